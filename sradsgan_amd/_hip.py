@@ -1,0 +1,57 @@
+"""ctypes binding of libsradsgan_hip.so (the C ABI declared in include/sradsgan_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the caller gets
+an exception.  PyTorch is only used to own device memory and streams; raw pointers cross the ABI.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsradsgan_hip.so')
+
+_vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/sradsgan_hip.h (tests check this)
+SIGNATURES = {
+    'srhip_last_error': (ctypes.c_char_p, []),
+    'srhip_abi_version': (_i, []),
+    'srhip_packed_ld': (_i, [_i]),
+    'srhip_pack_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'srhip_conv2d_fwd': (_i, [_vp] * 6 + [_i] * 12 + [_f, _i, _vp]),
+    'srhip_conv2d_dgrad': (_i, [_vp] * 3 + [_i] * 12 + [_vp]),
+    'srhip_conv2d_wgrad_workspace': (_sz, [_i] * 9),
+    'srhip_conv2d_wgrad': (_i, [_vp] * 4 + [_sz] + [_i] * 11 + [_vp]),
+    'srhip_colsum_workspace': (_sz, [_l, _i]),
+    'srhip_colsum': (_i, [_vp, _vp, _vp, _sz, _l, _i, _i, _vp]),
+    'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
+    'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises HipLibraryError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                'libsradsgan_hip.so is not built (%s). Build it with `make -C sradsgan_amd/csrc` or '
+                '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().srhip_last_error()
+        raise HipLibraryError('%s failed (%d): %s' % (what or 'srhip call', rc, msg.decode() if msg else '?'))

@@ -1,0 +1,48 @@
+// Shared host/device helpers for libsradsgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/sradsgan_hip.h"
+
+namespace srhip {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SRHIP_ERR_LAUNCH;
+  }
+  return SRHIP_OK;
+}
+
+#define SRHIP_REQUIRE(cond, ...)     \
+  do {                               \
+    if (!(cond)) {                   \
+      srhip::set_error(__VA_ARGS__); \
+      return SRHIP_ERR_ARG;          \
+    }                                \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// wave-wide reductions (64 lanes)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace srhip

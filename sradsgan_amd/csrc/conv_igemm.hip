@@ -1,0 +1,624 @@
+// Implicit-GEMM 2-D convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD, bitwise an fmaf chain -> fp32 parity with the
+// reference's ATen path at ~1e-6, see DESIGN.md "precision").
+//
+//   fprop / dgrad :  D[m][n] = sum_k A[m][k] * B[k][n]
+//        m = output pixel (n,ho,wo)      n = destination channel      k = (kh,kw,c_src)
+//        A is gathered on the fly from the NHWC source (im2col never materialised),
+//        B is the packed weight [KH*KW*Csrc][ld] (srhip_pack_weight).
+//        dgrad is the same kernel with flipped/transposed weights and a "divide by stride"
+//        gather (hnum = o - (KH-1-pad) + kh must be a multiple of the stride).
+//   wgrad         :  dW[co][(kh,kw,ci)] = sum_pixels dy[pix][co] * window(x)[pix][(kh,kw,ci)]
+//        both operands are pixel-major (k-major) in NHWC, so they stream straight into the
+//        [k][m] / [k][n] LDS images; split-K over pixels, deterministic two-pass reduce.
+//
+// Tiling: 256 threads = 4 wave64s; block tile BM x BN, K step 16, double-buffered LDS with the next
+// tile's global loads in flight during the MFMAs; every wave owns a (BM/WM)x(BN/WN) sub-tile built
+// from 32x32 MFMA tiles.  LDS images are k-major so that a wave's MFMA operand fetch is 32
+// consecutive dwords per half-wave (conflict-free ds_read_b32).
+#include "common.h"
+
+namespace srhip {
+
+constexpr int BK = 16;
+
+struct ConvGeom {
+  int N, H, W, C;    // source tensor: N x H x W x C (row stride ldx)
+  int Ho, Wo, K;     // destination tensor: N x Ho x Wo x K (row stride ldy)
+  int KH, KW;
+  int so, pad, dv;   // source coordinate = (o*so - pad + k) / dv, valid only when divisible
+  int ldx, ldy, ldr, ldw;
+  int Ktot;          // KH*KW*C
+  int M;             // N*Ho*Wo
+  float slope;
+  int flags;
+  int accumulate;
+};
+
+__device__ inline f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// -------------------------------------------------------------------------------------------- //
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void igemm_fprop_kernel(const float* __restrict__ src,
+                                                           const float* __restrict__ wt,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ residual,
+                                                           const float* __restrict__ rowscale,
+                                                           float* __restrict__ dst, ConvGeom g) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + 2, LDB = BN + 4;
+  constexpr int AR = BM / 64;
+  constexpr int BVEC = BK * BN / 4;            // float4s in one B tile
+  constexpr int BV = (BVEC + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDA + 2 * BK * LDB];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int ntn = (g.K + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn;
+  const int tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread im2col row bookkeeping (fixed for the whole K loop) ----
+  const int arow = tid >> 2, kq = tid & 3;
+  int hb[AR], wb[AR], pb[AR];
+  const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + arow + 64 * i;
+    if (m < g.M) {
+      int n = m / HoWo;
+      int rem = m - n * HoWo;
+      int ho = rem / g.Wo;
+      int wo = rem - ho * g.Wo;
+      hb[i] = ho * g.so - g.pad;
+      wb[i] = wo * g.so - g.pad;
+      pb[i] = n * g.H * g.W;
+    } else {
+      hb[i] = -(1 << 28);
+      wb[i] = 0;
+      pb[i] = 0;
+    }
+  }
+
+  float4 ra[AR];
+  float4 rb[BV];
+
+  auto gather1 = [&](int i, int k) -> float {
+    if (k >= g.Ktot) return 0.f;
+    int tap = k / g.C;
+    int c = k - tap * g.C;
+    int kh = tap / g.KW;
+    int kw = tap - kh * g.KW;
+    int hn = hb[i] + kh, wn = wb[i] + kw;
+    if (hn < 0 || wn < 0) return 0.f;
+    int hs = hn, ws = wn;
+    if (g.dv > 1) {
+      hs = hn / g.dv;
+      ws = wn / g.dv;
+      if (hs * g.dv != hn || ws * g.dv != wn) return 0.f;
+    }
+    if (hs >= g.H || ws >= g.W) return 0.f;
+    return src[(size_t)(pb[i] + hs * g.W + ws) * g.ldx + c];
+  };
+
+  auto load_tiles = [&](int kc) {
+    const int k = kc * BK + kq * 4;
+    if (VEC) {
+      int tap = k / g.C;
+      int c = k - tap * g.C;
+      int kh = tap / g.KW;
+      int kw = tap - kh * g.KW;
+      const bool kok = k < g.Ktot;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int hn = hb[i] + kh, wn = wb[i] + kw;
+        bool ok = kok && hn >= 0 && wn >= 0;
+        int hs = hn, ws = wn;
+        if (g.dv > 1) {
+          hs = hn / g.dv;
+          ws = wn / g.dv;
+          ok = ok && (hs * g.dv == hn) && (ws * g.dv == wn);
+        }
+        ok = ok && hs < g.H && ws < g.W;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(src + (size_t)(pb[i] + hs * g.W + ws) * g.ldx + c)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        ra[i].x = gather1(i, k);
+        ra[i].y = gather1(i, k + 1);
+        ra[i].z = gather1(i, k + 2);
+        ra[i].w = gather1(i, k + 3);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      int idx = tid + 256 * j;
+      int brow = idx / (BN / 4), bc = idx - brow * (BN / 4);
+      int kk = kc * BK + brow, col = n0 + bc * 4;
+      bool ok = (BVEC % 256 == 0 || idx < BVEC) && kk < g.Ktot && col < g.ldw;
+      rb[j] = ok ? *reinterpret_cast<const float4*>(wt + (size_t)kk * g.ldw + col)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* a = As + buf * BK * LDA + (kq * 4) * LDA + arow;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      a[0 * LDA + 64 * i] = ra[i].x;
+      a[1 * LDA + 64 * i] = ra[i].y;
+      a[2 * LDA + 64 * i] = ra[i].z;
+      a[3 * LDA + 64 * i] = ra[i].w;
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      int idx = tid + 256 * j;
+      if (BVEC % 256 == 0 || idx < BVEC) {
+        int brow = idx / (BN / 4), bc = idx - brow * (BN / 4);
+        *reinterpret_cast<float4*>(Bs + buf * BK * LDB + brow * LDB + bc * 4) = rb[j];
+      }
+    }
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int kl = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  const int nk = (g.Ktot + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) load_tiles(kc + 1);
+    const float* a = As + buf * BK * LDA + kl * LDA + wm * WTM + l31;
+    const float* b = Bs + buf * BK * LDB + kl * LDB + wn * WTN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * LDA + t * 32];
+#pragma unroll
+      for (int u = 0; u < TN; ++u) bv[u] = b[kk * 2 * LDB + u * 32];
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = mfma32(av[t], bv[u], acc[t][u]);
+    }
+    if (kc + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = n0 + wn * WTN + u * 32 + l31;
+    const bool nok = n < g.K;
+    const float bval = (nok && (g.flags & SRHIP_EPI_BIAS)) ? bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (nok && m < g.M) {
+          float v = acc[t][u][r];
+          if (g.flags & SRHIP_EPI_ROWSCALE) v *= rowscale[m];
+          v += bval;
+          if (g.flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
+          if (g.flags & SRHIP_EPI_RESIDUAL) v += residual[(size_t)m * g.ldr + n];
+          float* o = dst + (size_t)m * g.ldy + n;
+          if (g.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------- //
+// wgrad: rows = co, cols = kcol = (kh,kw,ci), reduction = pixels [p_begin, p_end) of this split.
+template <int BM, int BN, int WM, int WN, bool VA, bool VB>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ dy,
+                                                           float* __restrict__ partial, ConvGeom g,
+                                                           int nsplit, int chunks_per_split) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int AVEC = BK * BM / 4, BVEC = BK * BN / 4;
+  constexpr int AV = (AVEC + 255) / 256, BV = (BVEC + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDA + 2 * BK * LDB];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int ntn = (g.Ktot + BN - 1) / BN;
+  const int ntm = (g.K + BM - 1) / BM;
+  int bid = blockIdx.x;
+  const int tile_n = bid % ntn;
+  bid /= ntn;
+  const int tile_m = bid % ntm;
+  const int split = bid / ntm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HoWo = g.Ho * g.Wo;
+
+  // loop-invariant decode of this thread's B columns (kcol -> tap, ci)
+  int b_kh[BV][4], b_kw[BV][4], b_ci[BV][4];
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    int idx = tid + 256 * j;
+    int brow = idx / (BN / 4), bc = idx - brow * (BN / 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int kcol = n0 + bc * 4 + e;
+      if (kcol < g.Ktot) {
+        int tap = kcol / g.C;
+        b_ci[j][e] = kcol - tap * g.C;
+        b_kh[j][e] = tap / g.KW;
+        b_kw[j][e] = tap - b_kh[j][e] * g.KW;
+      } else {
+        b_ci[j][e] = 0;
+        b_kh[j][e] = -(1 << 28);
+        b_kw[j][e] = 0;
+      }
+    }
+  }
+
+  float4 ra[AV], rb[BV];
+  const int c_begin = split * chunks_per_split;
+  const int nchunks_total = (g.M + BK - 1) / BK;
+  const int c_end = min(c_begin + chunks_per_split, nchunks_total);
+
+  auto load_tiles = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      int idx = tid + 256 * j;
+      int arow = idx / (BM / 4), ac = idx - arow * (BM / 4);
+      int p = kc * BK + arow, co = m0 + ac * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((AVEC % 256 == 0 || idx < AVEC) && p < g.M) {
+        const float* s = dy + (size_t)p * g.ldy + co;
+        if (VA) {
+          if (co < g.K) v = *reinterpret_cast<const float4*>(s);
+        } else {
+          if (co + 0 < g.K) v.x = s[0];
+          if (co + 1 < g.K) v.y = s[1];
+          if (co + 2 < g.K) v.z = s[2];
+          if (co + 3 < g.K) v.w = s[3];
+        }
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      int idx = tid + 256 * j;
+      int brow = idx / (BN / 4);
+      int p = kc * BK + brow;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((BVEC % 256 == 0 || idx < BVEC) && p < g.M) {
+        int n = p / HoWo;
+        int rem = p - n * HoWo;
+        int ho = rem / g.Wo;
+        int wo = rem - ho * g.Wo;
+        int hbase = ho * g.so - g.pad, wbase = wo * g.so - g.pad;
+        int pbase = n * g.H * g.W;
+        if (VB) {
+          int hi = hbase + b_kh[j][0], wi = wbase + b_kw[j][0];
+          if (hi >= 0 && wi >= 0 && hi < g.H && wi < g.W)
+            v = *reinterpret_cast<const float4*>(x + (size_t)(pbase + hi * g.W + wi) * g.ldx + b_ci[j][0]);
+        } else {
+          float e4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int hi = hbase + b_kh[j][e], wi = wbase + b_kw[j][e];
+            e4[e] = (hi >= 0 && wi >= 0 && hi < g.H && wi < g.W)
+                        ? x[(size_t)(pbase + hi * g.W + wi) * g.ldx + b_ci[j][e]]
+                        : 0.f;
+          }
+          v = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      int idx = tid + 256 * j;
+      if (AVEC % 256 == 0 || idx < AVEC) {
+        int arow = idx / (BM / 4), ac = idx - arow * (BM / 4);
+        *reinterpret_cast<float4*>(As + buf * BK * LDA + arow * LDA + ac * 4) = ra[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      int idx = tid + 256 * j;
+      if (BVEC % 256 == 0 || idx < BVEC) {
+        int brow = idx / (BN / 4), bc = idx - brow * (BN / 4);
+        *reinterpret_cast<float4*>(Bs + buf * BK * LDB + brow * LDB + bc * 4) = rb[j];
+      }
+    }
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int kl = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  if (c_begin < c_end) {
+    load_tiles(c_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      const int buf = (kc - c_begin) & 1;
+      if (kc + 1 < c_end) load_tiles(kc + 1);
+      const float* a = As + buf * BK * LDA + kl * LDA + wm * WTM + l31;
+      const float* b = Bs + buf * BK * LDB + kl * LDB + wn * WTN + l31;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * LDA + t * 32];
+#pragma unroll
+        for (int u = 0; u < TN; ++u) bv[u] = b[kk * 2 * LDB + u * 32];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32(av[t], bv[u], acc[t][u]);
+      }
+      if (kc + 1 < c_end) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = partial + (size_t)split * g.K * g.Ktot;
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = n0 + wn * WTN + u * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (n < g.Ktot && m < g.K) out[(size_t)m * g.Ktot + n] = acc[t][u][r];
+      }
+  }
+}
+
+// partial[s][co][(kh,kw,ci)] --sum over s--> dw[co][ci][kh][kw]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit,
+                                    int cout, int cin, int khkw, int ktot) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = cout * ktot;
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int i = 0; i < nsplit; ++i) s += partial[(size_t)i * total + idx];
+  int co = idx / ktot, kcol = idx - co * ktot;
+  int tap = kcol / cin, ci = kcol - tap * cin;
+  dw[((size_t)co * cin + ci) * khkw + tap] = s;
+}
+
+// OIHW -> packed GEMM operand (see header)
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout, int cin,
+                                   int kh, int kw, int mode, int ld) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int csrc = mode == 0 ? cin : cout;
+  int cdst = mode == 0 ? cout : cin;
+  int rows = kh * kw * csrc;
+  if (idx >= rows * ld) return;
+  int row = idx / ld, col = idx - row * ld;
+  float v = 0.f;
+  if (col < cdst) {
+    int tap = row / csrc, cs = row - tap * csrc;
+    int a = tap / kw, b = tap - a * kw;
+    if (mode == 0)
+      v = w[(((size_t)col * cin + cs) * kh + a) * kw + b];
+    else
+      v = w[(((size_t)cs * cin + col) * kh + (kh - 1 - a)) * kw + (kw - 1 - b)];
+  }
+  packed[idx] = v;
+}
+
+// -------------------------------------------------------------------------------------------- //
+template <int BM, int BN, int WM, int WN>
+static int launch_fprop(const float* src, const float* wt, const float* bias, const float* residual,
+                        const float* rowscale, float* dst, const ConvGeom& g, bool vec, hipStream_t st) {
+  int blocks = cdiv(g.M, BM) * cdiv(g.K, BN);
+  if (vec)
+    hipLaunchKernelGGL((igemm_fprop_kernel<BM, BN, WM, WN, true>), dim3(blocks), dim3(256), 0, st, src, wt, bias,
+                       residual, rowscale, dst, g);
+  else
+    hipLaunchKernelGGL((igemm_fprop_kernel<BM, BN, WM, WN, false>), dim3(blocks), dim3(256), 0, st, src, wt, bias,
+                       residual, rowscale, dst, g);
+  return check_launch("igemm_fprop");
+}
+
+static int run_fprop(const float* src, const float* wt, const float* bias, const float* residual,
+                     const float* rowscale, float* dst, const ConvGeom& g, hipStream_t st) {
+  const bool vec = (g.C % 4 == 0) && (g.ldx % 4 == 0);
+  if (g.M <= 0) return SRHIP_OK;
+  if (g.K <= 32) return launch_fprop<128, 32, 4, 1>(src, wt, bias, residual, rowscale, dst, g, vec, st);
+  // keep >= ~2 waves of blocks over the 256 CUs; shrink the tile when the problem is small
+  long blocks128 = (long)cdiv(g.M, 128) * cdiv(g.K, 128);
+  if (g.K >= 128 && blocks128 >= 512) return launch_fprop<128, 128, 2, 2>(src, wt, bias, residual, rowscale, dst, g, vec, st);
+  long blocks64n = (long)cdiv(g.M, 128) * cdiv(g.K, 64);
+  if (blocks64n >= 512) return launch_fprop<128, 64, 2, 2>(src, wt, bias, residual, rowscale, dst, g, vec, st);
+  return launch_fprop<64, 64, 2, 2>(src, wt, bias, residual, rowscale, dst, g, vec, st);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad(const float* x, const float* dy, float* partial, const ConvGeom& g, int nsplit, int cps,
+                        bool va, bool vb, hipStream_t st) {
+  int blocks = cdiv(g.K, BM) * cdiv(g.Ktot, BN) * nsplit;
+#define SRHIP_WG(VA_, VB_)                                                                                     \
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BM, BN, WM, WN, VA_, VB_>), dim3(blocks), dim3(256), 0, st, x, dy, \
+                     partial, g, nsplit, cps)
+  if (va && vb)
+    SRHIP_WG(true, true);
+  else if (va)
+    SRHIP_WG(true, false);
+  else if (vb)
+    SRHIP_WG(false, true);
+  else
+    SRHIP_WG(false, false);
+#undef SRHIP_WG
+  return check_launch("igemm_wgrad");
+}
+
+struct WgradPlan {
+  int bm, bn, nsplit, chunks_per_split;
+};
+
+static WgradPlan plan_wgrad(int M, int cout, int ktot) {
+  WgradPlan p;
+  p.bm = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  p.bn = p.bm == 32 ? 128 : 64;
+  long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
+  int nchunks = cdiv(M, BK);
+  long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU overall
+  long maxsplit = (nchunks + 15) / 16;             // at least 16 chunks (256 pixels) per split
+  long ns = want < 1 ? 1 : want;
+  if (ns > maxsplit) ns = maxsplit;
+  if (ns < 1) ns = 1;
+  p.chunks_per_split = (int)((nchunks + ns - 1) / ns);
+  p.nsplit = cdiv(nchunks, p.chunks_per_split);
+  return p;
+}
+
+}  // namespace srhip
+
+using namespace srhip;
+
+extern "C" {
+
+int srhip_packed_ld(int cdst) { return ((cdst + 31) / 32) * 32; }
+
+int srhip_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, void* stream) {
+  SRHIP_REQUIRE(w && packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1),
+                "pack_weight: bad argument");
+  int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
+  int ld = srhip_packed_ld(cdst);
+  long total = (long)kh * kw * csrc * ld;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, packed, cout,
+                     cin, kh, kw, mode, ld);
+  return check_launch("pack_weight");
+}
+
+int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+                     const float* rowscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,
+                     int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, void* stream) {
+  SRHIP_REQUIRE(x && packed && y, "conv2d_fwd: null tensor");
+  SRHIP_REQUIRE(n >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_fwd: bad geometry");
+  SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_fwd: row stride smaller than channel count");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_BIAS) || bias, "conv2d_fwd: EPI_BIAS without bias");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_RESIDUAL) || (residual && ldr >= cout), "conv2d_fwd: EPI_RESIDUAL without residual");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_ROWSCALE) || rowscale, "conv2d_fwd: EPI_ROWSCALE without rowscale");
+  ConvGeom g;
+  g.N = n; g.H = h; g.W = w; g.C = cin;
+  g.Ho = (h + 2 * pad - kh) / stride + 1;
+  g.Wo = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(g.Ho > 0 && g.Wo > 0, "conv2d_fwd: empty output");
+  g.K = cout; g.KH = kh; g.KW = kw; g.so = stride; g.pad = pad; g.dv = 1;
+  g.ldx = ldx; g.ldy = ldy; g.ldr = ldr; g.ldw = srhip_packed_ld(cout);
+  g.Ktot = kh * kw * cin;
+  long M = (long)n * g.Ho * g.Wo;
+  SRHIP_REQUIRE(M < (1L << 31) && (long)n * h * w < (1L << 31), "conv2d_fwd: pixel count overflows int32");
+  g.M = (int)M; g.slope = slope; g.flags = flags; g.accumulate = 0;
+  return run_fprop(x, packed, bias, residual, rowscale, y, g, as_stream(stream));
+}
+
+int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, int h, int w, int cin, int cout,
+                       int kh, int kw, int stride, int pad, int ldy, int ldx, int accumulate, void* stream) {
+  SRHIP_REQUIRE(dy && packed && dx, "conv2d_dgrad: null tensor");
+  SRHIP_REQUIRE(n >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_dgrad: bad geometry");
+  SRHIP_REQUIRE(pad <= kh - 1 && pad <= kw - 1, "conv2d_dgrad: pad > kernel-1 unsupported");
+  SRHIP_REQUIRE(ldy >= cout && ldx >= cin, "conv2d_dgrad: row stride smaller than channel count");
+  ConvGeom g;
+  // source = dy (N x Ho x Wo x Cout), destination = dx (N x H x W x Cin)
+  g.N = n;
+  g.H = (h + 2 * pad - kh) / stride + 1;
+  g.W = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(g.H > 0 && g.W > 0, "conv2d_dgrad: empty dy");
+  g.C = cout; g.Ho = h; g.Wo = w; g.K = cin; g.KH = kh; g.KW = kw;
+  g.so = 1; g.pad = kh - 1 - pad; g.dv = stride;
+  SRHIP_REQUIRE(kh == kw, "conv2d_dgrad: square kernels only");
+  g.ldx = ldy; g.ldy = ldx; g.ldr = 0; g.ldw = srhip_packed_ld(cin);
+  g.Ktot = kh * kw * cout;
+  long M = (long)n * h * w;
+  SRHIP_REQUIRE(M < (1L << 31), "conv2d_dgrad: pixel count overflows int32");
+  g.M = (int)M; g.slope = 0.f; g.flags = 0; g.accumulate = accumulate ? 1 : 0;
+  return run_fprop(dy, packed, nullptr, nullptr, nullptr, dx, g, as_stream(stream));
+}
+
+size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  long M = (long)n * ho * wo;
+  if (M <= 0) return 0;
+  WgradPlan p = plan_wgrad((int)M, cout, kh * kw * cin);
+  return (size_t)p.nsplit * cout * kh * kw * cin * sizeof(float);
+}
+
+int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
+                       int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
+                       void* stream) {
+  SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_wgrad: bad geometry");
+  SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_wgrad: row stride smaller than channel count");
+  ConvGeom g;
+  g.N = n; g.H = h; g.W = w; g.C = cin;
+  g.Ho = (h + 2 * pad - kh) / stride + 1;
+  g.Wo = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(g.Ho > 0 && g.Wo > 0, "conv2d_wgrad: empty output");
+  g.K = cout; g.KH = kh; g.KW = kw; g.so = stride; g.pad = pad; g.dv = 1;
+  g.ldx = ldx; g.ldy = ldy; g.ldr = 0; g.ldw = 0; g.Ktot = kh * kw * cin;
+  long M = (long)n * g.Ho * g.Wo;
+  SRHIP_REQUIRE(M < (1L << 31) && (long)n * h * w < (1L << 31), "conv2d_wgrad: pixel count overflows int32");
+  g.M = (int)M; g.slope = 0.f; g.flags = 0; g.accumulate = 0;
+  WgradPlan p = plan_wgrad(g.M, cout, g.Ktot);
+  size_t need = (size_t)p.nsplit * cout * g.Ktot * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_error("conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return SRHIP_ERR_WORKSPACE;
+  }
+  float* partial = static_cast<float*>(workspace);
+  hipStream_t st = as_stream(stream);
+  const bool va = (cout % 4 == 0) && (ldy % 4 == 0);
+  const bool vb = (cin % 4 == 0) && (ldx % 4 == 0);
+  int rc;
+  if (p.bm == 128)
+    rc = launch_wgrad<128, 64, 2, 2>(x, dy, partial, g, p.nsplit, p.chunks_per_split, va, vb, st);
+  else if (p.bm == 64)
+    rc = launch_wgrad<64, 64, 2, 2>(x, dy, partial, g, p.nsplit, p.chunks_per_split, va, vb, st);
+  else
+    rc = launch_wgrad<32, 128, 1, 4>(x, dy, partial, g, p.nsplit, p.chunks_per_split, va, vb, st);
+  if (rc) return rc;
+  long total = (long)cout * g.Ktot;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, dw, p.nsplit, cout, cin,
+                     kh * kw, g.Ktot);
+  return check_launch("wgrad_reduce");
+}
+
+}  // extern "C"

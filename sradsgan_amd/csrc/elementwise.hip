@@ -1,0 +1,198 @@
+// HBM-bound pieces of the SRADSGAN step: activation backward, pixel shuffle, column sums.
+// All are one pass over the tensor with 16-byte accesses; roofline = HBM bandwidth.
+#include "common.h"
+
+#include <string.h>
+
+namespace srhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__global__ void lrelu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ dx,
+                                 long n4, float slope) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    float4 g = dy[i], v = y[i];
+    g.x = v.x > 0.f ? g.x : g.x * slope;
+    g.y = v.y > 0.f ? g.y : g.y * slope;
+    g.z = v.z > 0.f ? g.z : g.z * slope;
+    g.w = v.w > 0.f ? g.w : g.w * slope;
+    dx[i] = g;
+  }
+}
+__global__ void lrelu_bwd_tail_kernel(const float* dy, const float* y, float* dx, long begin, long n, float slope) {
+  long i = begin + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// NHWC pixel shuffle. One thread per 4 output channels: out[n, h*r+i, w*r+j, c..c+3] gathers
+// in[n,h,w,(c+e)*r*r + i*r + j], e=0..3 (stride r*r apart) -- reads of a wave cover the whole
+// r*r*C contiguous source row, writes are fully coalesced.
+__global__ void pixel_shuffle_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w,
+                                         int c, int r, float slope, int act) {
+  long total = (long)n * h * r * w * r * (c / 4);
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int c4 = (int)(idx % (c / 4));
+  long pix = idx / (c / 4);
+  int ow = (int)(pix % (w * r));
+  long t = pix / (w * r);
+  int oh = (int)(t % (h * r));
+  int b = (int)(t / (h * r));
+  int hh = oh / r, i = oh - hh * r, ww = ow / r, j = ow - ww * r;
+  const float* s = in + ((size_t)(b * h + hh) * w + ww) * ((size_t)c * r * r) + (size_t)(c4 * 4) * r * r + i * r + j;
+  float4 v;
+  v.x = s[0];
+  v.y = s[r * r];
+  v.z = s[2 * r * r];
+  v.w = s[3 * r * r];
+  if (act) {
+    v.x = v.x > 0.f ? v.x : v.x * slope;
+    v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope;
+    v.w = v.w > 0.f ? v.w : v.w * slope;
+  }
+  reinterpret_cast<float4*>(out)[idx] = v;
+}
+
+__global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv,
+                                         float* __restrict__ din, int n, int h, int w, int c, int r, float slope,
+                                         int act) {
+  long total = (long)n * h * r * w * r * (c / 4);
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int c4 = (int)(idx % (c / 4));
+  long pix = idx / (c / 4);
+  int ow = (int)(pix % (w * r));
+  long t = pix / (w * r);
+  int oh = (int)(t % (h * r));
+  int b = (int)(t / (h * r));
+  int hh = oh / r, i = oh - hh * r, ww = ow / r, j = ow - ww * r;
+  float4 g = reinterpret_cast<const float4*>(dout)[idx];
+  if (act) {
+    float4 v = reinterpret_cast<const float4*>(outv)[idx];
+    g.x = v.x > 0.f ? g.x : g.x * slope;
+    g.y = v.y > 0.f ? g.y : g.y * slope;
+    g.z = v.z > 0.f ? g.z : g.z * slope;
+    g.w = v.w > 0.f ? g.w : g.w * slope;
+  }
+  float* d = din + ((size_t)(b * h + hh) * w + ww) * ((size_t)c * r * r) + (size_t)(c4 * 4) * r * r + i * r + j;
+  d[0] = g.x;
+  d[r * r] = g.y;
+  d[2 * r * r] = g.z;
+  d[3 * r * r] = g.w;
+}
+
+// column sums of a [rows][ld] matrix, first C columns; stage 1: each block reduces ROWS_PER_BLOCK rows
+constexpr int CS_ROWS = 512;
+__global__ void colsum_stage1(const float* __restrict__ dy, float* __restrict__ partial, long rows, int c, int ld) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int cols_per_pass = c < 256 ? c : 256;     // threads along columns
+  const int rlanes = 256 / cols_per_pass;          // threads along rows (>=1)
+  const long r0 = (long)blockIdx.x * CS_ROWS;
+  const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+  for (int cbase = 0; cbase < c; cbase += cols_per_pass) {
+    int col = cbase + tid % cols_per_pass;
+    int rl = tid / cols_per_pass;
+    float s = 0.f;
+    if (col < c && rl < rlanes)
+      for (long r = r0 + rl; r < r1; r += rlanes) s += dy[(size_t)r * ld + col];
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && col < c) {
+      float t = 0.f;
+      for (int k = 0; k < rlanes; ++k) t += red[k * cols_per_pass + tid];
+      partial[(size_t)blockIdx.x * c + col] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk, int c) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * c + col];
+  out[col] = s;
+}
+
+}  // namespace srhip
+
+using namespace srhip;
+
+extern "C" {
+
+const char* srhip_last_error(void) { return g_err; }
+int srhip_abi_version(void) { return 1; }
+
+int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream) {
+  SRHIP_REQUIRE(dy && y && dx && count >= 0, "lrelu_bwd: bad argument");
+  if (count == 0) return SRHIP_OK;
+  hipStream_t st = as_stream(stream);
+  bool aligned = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx)) & 15) == 0;
+  long n4 = aligned ? count / 4 : 0;
+  if (n4 > 0) {
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)dy, (const float4*)y,
+                       (float4*)dx, n4, slope);
+  }
+  long done = n4 * 4;
+  if (done < count)
+    hipLaunchKernelGGL(lrelu_bwd_tail_kernel, dim3(cdiv(count - done, 256)), dim3(256), 0, st, dy, y, dx, done, count,
+                       slope);
+  return check_launch("lrelu_bwd");
+}
+
+int srhip_pixel_shuffle_fwd(const float* in, float* out, int n, int h, int w, int cout, int r, float slope,
+                            int apply_act, void* stream) {
+  SRHIP_REQUIRE(in && out && n >= 0 && h > 0 && w > 0 && cout > 0 && r > 0, "pixel_shuffle_fwd: bad argument");
+  SRHIP_REQUIRE(cout % 4 == 0, "pixel_shuffle_fwd: output channels must be a multiple of 4");
+  long total = (long)n * h * r * w * r * (cout / 4);
+  if (total == 0) return SRHIP_OK;
+  hipLaunchKernelGGL(pixel_shuffle_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), in, out, n, h,
+                     w, cout, r, slope, apply_act);
+  return check_launch("pixel_shuffle_fwd");
+}
+
+int srhip_pixel_shuffle_bwd(const float* dout, const float* out, float* din, int n, int h, int w, int cout, int r,
+                            float slope, int apply_act, void* stream) {
+  SRHIP_REQUIRE(dout && din && (out || !apply_act) && n >= 0 && h > 0 && w > 0 && cout > 0 && r > 0,
+                "pixel_shuffle_bwd: bad argument");
+  SRHIP_REQUIRE(cout % 4 == 0, "pixel_shuffle_bwd: output channels must be a multiple of 4");
+  long total = (long)n * h * r * w * r * (cout / 4);
+  if (total == 0) return SRHIP_OK;
+  hipLaunchKernelGGL(pixel_shuffle_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), dout, out, din,
+                     n, h, w, cout, r, slope, apply_act);
+  return check_launch("pixel_shuffle_bwd");
+}
+
+size_t srhip_colsum_workspace(long rows, int c) {
+  long nblk = (rows + CS_ROWS - 1) / CS_ROWS;
+  return (size_t)(nblk > 0 ? nblk : 1) * c * sizeof(float);
+}
+
+int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_bytes, long rows, int c, int ld,
+                 void* stream) {
+  SRHIP_REQUIRE(dy && db && rows > 0 && c > 0 && ld >= c, "colsum: bad argument");
+  size_t need = srhip_colsum_workspace(rows, c);
+  if (!workspace || workspace_bytes < need) {
+    set_error("colsum: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return SRHIP_ERR_WORKSPACE;
+  }
+  int nblk = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld);
+  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(c, 256)), dim3(256), 0, st, (const float*)workspace, db, nblk, c);
+  return check_launch("colsum");
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""HIP implicit-GEMM conv (through the C ABI) vs a plain PyTorch fp32 CPU reference of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # fp32 MFMA is an exact fmaf chain; differences are summation-order only
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad
+    (2, 64, 12, 10, 256, 3, 1, 1),      # RAB conv1 (sradsgan.py:222)
+    (2, 256, 12, 10, 64, 3, 1, 1),      # RAB conv2 (:223)
+    (1, 64, 54, 54, 64, 1, 1, 0),       # 1x1 tail (:233) at the real LR size
+    (3, 3, 17, 19, 64, 3, 1, 1),        # head conv, Cin=3, ragged sizes (:427)
+    (2, 64, 16, 16, 3, 3, 1, 1),        # tail conv, Cout=3 (:448)
+    (2, 64, 16, 16, 64, 3, 2, 1),       # discriminator stride 2, even input (:476)
+    (2, 128, 27, 27, 128, 3, 2, 1),     # stride 2, odd input (27 -> 14)
+    (2, 512, 14, 14, 1, 3, 1, 1),       # discriminator output conv, Cout=1 (:503)
+    (2, 2, 9, 11, 1, 7, 1, 3),          # SLAM 7x7 (:136)
+    (1, 192, 8, 8, 64, 1, 1, 0),        # MSB fuse conv (:336)
+    (2, 64, 6, 7, 576, 3, 1, 1),        # x3 upsampler conv (:384)
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd_bwd_matches_torch(case):
+    from sradsgan_amd import ops
+    n, cin, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.leaky_relu(F.conv2d(xr, wr, br, s, p), 0.2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+
+    dev = torch.device('cuda:0')
+    xg, wg, bg = (t.clone().to(dev).requires_grad_() for t in (x, wt, b))
+    yg = ops.conv2d(xg, wg, bg, s, p, act_slope=0.2)
+    assert yg.shape == yr.shape
+    yg.backward(dy.to(dev))
+    assert _rel(yg, yr) < TOL
+    assert _rel(xg.grad, xr.grad) < TOL
+    assert _rel(wg.grad, wr.grad) < TOL
+    assert _rel(bg.grad, br.grad) < TOL
+
+
+def test_conv_residual_epilogue():
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x, res = torch.randn(2, 64, 9, 9, generator=g), torch.randn(2, 64, 9, 9, generator=g)
+    wt, b = torch.randn(64, 64, 1, 1, generator=g) * 0.1, torch.randn(64, generator=g)
+    ref = F.conv2d(x, wt, b) + res
+    dev = torch.device('cuda:0')
+    xg, rg = x.to(dev).requires_grad_(), res.to(dev).requires_grad_()
+    out = ops.conv2d(xg, wt.to(dev), b.to(dev), 1, 0, residual=rg)
+    assert _rel(out, ref) < TOL
+    out.sum().backward()
+    assert _rel(rg.grad, torch.ones_like(res)) < 1e-7
+
+
+def test_conv_double_backward_matches_torch():
+    """Second-order path used by the gradient penalty (sradsgan.py:621,639)."""
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, 12, 12, generator=g)
+    w1, b1 = torch.randn(16, 3, 3, 3, generator=g) * 0.3, torch.randn(16, generator=g) * 0.1
+    w2, b2 = torch.randn(8, 16, 3, 3, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1
+
+    def run(conv, dev):
+        xx = x.to(dev).requires_grad_()
+        ps = [t.clone().to(dev).requires_grad_() for t in (w1, b1, w2, b2)]
+        h = conv(xx, ps[0], ps[1], 1, 1)
+        out = conv(h, ps[2], ps[3], 2, 1)
+        (gx,) = torch.autograd.grad(out, xx, torch.ones_like(out), create_graph=True)
+        pen = ((gx.norm(2, 1) - 1) ** 2).mean()
+        pen.backward()
+        return pen, [p.grad for p in ps]
+
+    pr, gr = run(lambda a, w, b, s, p: F.leaky_relu(F.conv2d(a, w, b, s, p), 0.2), torch.device('cpu'))
+    pg, gg = run(lambda a, w, b, s, p: ops.conv2d(a, w, b, s, p, act_slope=0.2), torch.device('cuda:0'))
+    assert abs(pr.item() - pg.item()) < 1e-5 * max(1.0, abs(pr.item()))
+    for a, b in zip(gg, gr):
+        assert _rel(a, b) < 5e-4
+
+
+def test_pixel_shuffle_index_exact(golden):
+    from sradsgan_amd import ops
+    import numpy as np
+    tab = golden('pixel_shuffle_index')
+    dev = torch.device('cuda:0')
+    for r in (2, 3):
+        c, h, w = 8, 5, 7
+        src = torch.arange(2 * c * r * r * h * w, dtype=torch.float32).reshape(2, c * r * r, h, w)
+        got = ops.pixel_shuffle_act(src.to(dev), r, None).cpu()
+        assert torch.equal(got, F.pixel_shuffle(src, r))           # integer-valued floats: exact
+        x = torch.randn(2, c * r * r, h, w)
+        xr, xg = x.clone().requires_grad_(), x.clone().to(dev).requires_grad_()
+        yr = F.leaky_relu(F.pixel_shuffle(xr, r), 0.01)
+        yg = ops.pixel_shuffle_act(xg, r, 0.01)
+        dy = torch.randn_like(yr)
+        yr.backward(dy), yg.backward(dy.to(dev))
+        assert torch.equal(yg.cpu(), yr.detach()) and torch.equal(xg.grad.cpu(), xr.grad)
+    # the committed reference table (c=2,h=3,w=4) through the same kernel needs C%4==0: use c=4 superset
+    for r in (2, 3):
+        c, h, w = 4, 3, 4
+        src = torch.arange(c * r * r * h * w, dtype=torch.float32).reshape(1, c * r * r, h, w)
+        got = ops.pixel_shuffle_act(src.to(dev), r, None).cpu().to(torch.int64).numpy()
+        assert np.array_equal(got[:, :2], tab['r%d' % r])
