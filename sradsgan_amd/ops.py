@@ -20,11 +20,16 @@ from . import _hip
 EPI_BIAS, EPI_LRELU, EPI_RESIDUAL, EPI_ROWSCALE = 1, 2, 4, 8
 CL = torch.channels_last
 
-_state = threading.local()
+class _State:
+    # a plain global, not threading.local: autograd runs Function.backward on its own device thread
+    skip_param_grads = False
+
+
+_state = _State()
 
 
 def _skip_param_grads():
-    return getattr(_state, 'skip_param_grads', False)
+    return _state.skip_param_grads
 
 
 @contextlib.contextmanager
@@ -312,3 +317,92 @@ class _PixelShuffleAct(Function):
 
 def pixel_shuffle_act(x, r, slope=None):
     return _PixelShuffleAct.apply(x, r, slope)
+
+
+# --------------------------------------------------------------------------------------------- #
+# attention / normalisation glue.  TRANSITIONAL: the functions below are still compositions of
+# torch device ops (ATen HIP kernels) around the HIP convs; each is being replaced by a fused HIP
+# kernel behind the same Python signature (DESIGN.md lists what is still on ATen).
+# --------------------------------------------------------------------------------------------- #
+
+
+def _mlp_1x1(v, fc1_w, fc2_w):
+    """v: [B,C,1,1]; the two bias-free 1x1 convs of CLAM (sradsgan.py:110-112) as matmuls."""
+    b, c = v.shape[0], v.shape[1]
+    hid = torch.relu(v.reshape(b, c) @ fc1_w.reshape(fc1_w.shape[0], c).t())
+    return (hid @ fc2_w.reshape(c, fc1_w.shape[0]).t()).reshape(b, c, 1, 1)
+
+
+def clam(x, fc1_w, fc2_w, pool_mode='Avg|Max'):
+    """sradsgan.py:117-127 / base_networks.py:387-403."""
+    logits = 0
+    if 'Avg' in pool_mode:
+        logits = logits + _mlp_1x1(x.mean((2, 3), keepdim=True), fc1_w, fc2_w)
+    if 'Max' in pool_mode:
+        logits = logits + _mlp_1x1(torch.nn.functional.adaptive_max_pool2d(x, 1), fc1_w, fc2_w)
+    return torch.sigmoid(logits) * x
+
+
+def slam(x, w7, pool_mode='Avg|Max'):
+    """sradsgan.py:141-151 / base_networks.py:440-457: the 7x7 (2->1) conv runs on the HIP igemm."""
+    maps = []
+    if 'Avg' in pool_mode:
+        maps.append(x.mean(dim=1, keepdim=True))
+    if 'Max' in pool_mode:
+        maps.append(x.max(dim=1, keepdim=True)[0])
+    pooled = torch.cat(maps, dim=1)
+    return torch.sigmoid(conv2d(pooled, w7, None, 1, w7.shape[-1] // 2)) * x
+
+
+def cgam(x, gamma):
+    """sradsgan.py:202-212; softmax(rowmax(E)-E) == softmax(-E) (shift invariance)."""
+    b, c, h, w = x.shape
+    xf = x.permute(0, 2, 3, 1).reshape(b, h * w, c)            # NHWC memory: free view [b, n, c]
+    energy = xf.transpose(1, 2) @ xf                            # [b, c, c]
+    att = torch.softmax(energy.max(dim=-1, keepdim=True)[0] - energy, dim=-1)
+    out = xf @ att.transpose(1, 2)                              # [b, n, c]
+    return gamma * out.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+
+
+def sgam(x, q, k, v, gamma):
+    """sradsgan.py:165-175 with q,k,v already projected (NHWC memory). Materialises N x N for now."""
+    b, c, h, w = x.shape
+    n = h * w
+    qf = q.permute(0, 2, 3, 1).reshape(b, n, -1)
+    kf = k.permute(0, 2, 3, 1).reshape(b, n, -1)
+    vf = v.permute(0, 2, 3, 1).reshape(b, n, c)
+    att = torch.softmax(qf @ kf.transpose(1, 2), dim=-1)        # [b, n(query), n(key)]
+    out = att @ vf                                              # [b, n, c]
+    return gamma * out.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+
+
+def batch_norm_act(x, bn, slope=None):
+    """Train-mode BatchNorm2d + LeakyReLU (sradsgan.py:478-479); updates running stats like
+    nn.BatchNorm2d (momentum 0.1, unbiased running_var).  Twice differentiable."""
+    if not bn.training:
+        raise NotImplementedError('the reference never puts the discriminator in eval() (SURVEY a11)')
+    n = x.numel() // x.shape[1]
+    mean = x.mean((0, 2, 3))
+    var = x.var((0, 2, 3), unbiased=False)
+    with torch.no_grad():
+        m = bn.momentum
+        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+        bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+        bn.num_batches_tracked += 1
+    inv = torch.rsqrt(var + bn.eps)
+    y = (x - mean.view(1, -1, 1, 1)) * (inv * bn.weight).view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+
+def max_pool2x2(x):
+    return torch.nn.functional.max_pool2d(x, 2, 2)
+
+
+def l1_mean(a, b):
+    """nn.L1Loss() (sradsgan.py:686,834,838)."""
+    return (a - b).abs().mean()
+
+
+def gp_penalty(grads):
+    """sradsgan.py:630-637: L2 norm over the channel dim (per pixel), LS penalty, mean."""
+    return (grads.norm(2, 1) - 1).pow(2).mean()

@@ -1,0 +1,173 @@
+"""HIP model graph vs the CPU oracle (pinned to the reference by tests/golden) on identical
+deterministic weights and inputs.  Tolerances: 1e-3 relative in fp32 (BASELINE.json north_star);
+observed differences are ~1e-5 because the MFMA path is exact fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sradsgan_ref as O
+from tests.parity_util import build_pair, rel_err, train_parity
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+TOL = 1e-3
+FLOOR = 1e-4          # gradients that are mathematically zero (e.g. SGAM key bias) are pure roundoff
+
+
+def _close(got, want, tol=TOL, msg=''):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(float(np.abs(want).max()), FLOOR)
+    err = float(np.abs(got - want).max())
+    assert err <= tol * scale, '%s: max abs err %.3e vs scale %.3e' % (msg, err, scale)
+
+
+def _module_case(golden, tag, hip_mod, ora_mod, x, grad_keys):
+    g = golden(tag)
+    O.det_init_(ora_mod, prefix=tag + '.')
+    hip_mod.load_state_dict(ora_mod.state_dict(), strict=True)
+    hip_mod.to(DEV)
+    xo = x.clone().requires_grad_(True)
+    xh = x.clone().to(DEV).requires_grad_(True)
+    dy = None
+    yo = ora_mod(xo)
+    yh = hip_mod(xh)
+    dy = O.det_fill(tag + '.dy', tuple(yo.shape), 1.0)
+    yo.backward(dy)
+    yh.backward(dy.to(DEV))
+    _close(yh.detach().cpu(), yo.detach(), msg='y vs oracle')
+    _close(xh.grad.cpu(), xo.grad, msg='dx vs oracle')
+    # and against the vectors recorded from the reference itself
+    _close(O.digest(yh), g['y'], msg='y vs reference')
+    _close(O.digest(xh.grad), g['dx'], msg='dx vs reference')
+    hp, op = dict(hip_mod.named_parameters()), dict(ora_mod.named_parameters())
+    for k in grad_keys:
+        _close(hp[k].grad.cpu(), op[k].grad, msg=k + ' vs oracle')
+        _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], msg=k + ' vs reference')
+
+
+X64 = lambda: O.det_fill('x64', (2, 64, 10, 12), 1.0)
+X3 = lambda: O.det_fill('x3', (2, 3, 10, 12), 0.5, 0.5)
+
+
+def test_clam(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'clam', M.CLAM(64), O.CLAM(64), X64(), ['fc1.weight', 'fc2.weight'])
+
+
+def test_slam(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'slam', M.SLAM(7), O.SLAM(7), X64(), ['conv1.weight'])
+
+
+def test_cgam(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'cgam', M.CGAM(64), O.CGAM(64), X64() * 0.3, ['gamma'])
+
+
+def test_sgam(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'sgam', M.SGAM(64), O.SGAM(64), X64(),
+                 ['gamma', 'query_conv.weight', 'key_conv.bias', 'value_conv.weight'])
+
+
+def test_rab(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'rab', M.RAB(64, 64), O.RAB(64, 64), X64(),
+                 ['conv1.weight', 'conv2.bias', 'ca.fc1.weight', 'sa.conv1.weight', 'conv.weight'])
+
+
+def test_resgroup(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'resgroup', M.ResGroup(M.RAB, n_blocks=2), O.ResGroup(O.RAB, n_blocks=2), X64(),
+                 ['RG.1.conv2.weight', 'ca.fc2.weight', 'sa.conv1.weight', 'conv.bias'])
+
+
+def test_msb(golden):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'msb', M.MSB(3, 64), O.MSB(3, 64), X3(),
+                 ['conv1.weight', 'conv2.0.weight', 'conv2.1.bias', 'conv.weight'])
+
+
+@pytest.mark.parametrize('s', [2, 3, 4, 9])
+def test_gab_up(golden, s):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'gabup_x%d' % s, M.GAB_UP(upscale_factor=s), O.GAB_UP(upscale_factor=s),
+                 X64()[:1, :, :6, :7] * 0.3,
+                 ['upsampling.0.weight', 'upsampling.0.bias', 'conv.weight', 'ca.gamma', 'sa.gamma'])
+
+
+@pytest.mark.parametrize('s', [2, 3, 4])
+def test_generator_small(golden, s):
+    from sradsgan_amd import model as M
+    _module_case(golden, 'gen_small_x%d' % s,
+                 M.GeneratorResNet(M.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s),
+                 O.GeneratorResNet(O.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s), X3()[:1],
+                 ['conv1.0.weight', 'res_groups.0.RG.0.conv1.weight', 'res_groups.1.conv.weight',
+                  'GAB_UP.upsampling.0.weight', 'MSB.conv.weight', 'conv3.0.bias'])
+
+
+def test_state_dict_keys_match_reference_contract():
+    from sradsgan_amd import model as M
+    g, og = M.GeneratorResNet(M.ResGroup, upscale_factor=4), O.GeneratorResNet(O.ResGroup, upscale_factor=4)
+    assert list(g.state_dict().keys()) == list(og.state_dict().keys()) and len(g.state_dict()) == 412
+    assert g.GAB_UP.upsampling[0] is g.GAB_UP.upsampling[3]
+    d, od = M.Discriminator(), O.Discriminator()
+    assert list(d.state_dict().keys()) == list(od.state_dict().keys()) and len(d.state_dict()) == 56
+    assert list(M.FeatureExtractor().state_dict().keys()) == list(O.FeatureExtractor().state_dict().keys())
+
+
+def test_discriminator_and_running_stats(golden):
+    from sradsgan_amd import model as M
+    g = golden('disc')
+    od = O.Discriminator()
+    O.det_init_(od, prefix='D.')
+    hd = M.Discriminator()
+    hd.load_state_dict(od.state_dict())
+    hd.to(DEV)
+    img = O.det_fill('dimg', (2, 3, 32, 32), 0.5, 0.5)
+    xh = img.clone().to(DEV).requires_grad_(True)
+    out = hd(xh)
+    out.backward(O.det_fill('D.dy', tuple(out.shape), 1.0).to(DEV))
+    _close(O.digest(out), g['y'], msg='y')
+    _close(O.digest(xh.grad), g['dx'], 2e-3, msg='dx')
+    sd = hd.state_dict()
+    for k, gk in [('model.3.running_mean', 'rm3'), ('model.3.running_var', 'rv3'),
+                  ('model.23.running_mean', 'rm23'), ('model.23.running_var', 'rv23')]:
+        _close(O.digest(sd[k]), g[gk], msg=k)
+    assert int(sd['model.3.num_batches_tracked']) == int(g['nbt'])
+    hp = dict(hd.named_parameters())
+    for k in ['model.0.weight', 'model.3.weight', 'model.17.fc1.weight', 'model.18.conv1.weight',
+              'model.25.weight', 'model.22.bias']:
+        _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], 2e-3, msg=k)
+
+
+def test_gradient_penalty_double_backward(golden):
+    from sradsgan_amd import model as M
+    from sradsgan_amd.train_step import TrainStep
+    g = golden('gradient_penalty')
+    od = O.Discriminator()
+    O.det_init_(od, prefix='D.')
+    hd = M.Discriminator()
+    hd.load_state_dict(od.state_dict())
+    hd.to(DEV)
+    step = TrainStep(torch.nn.Linear(1, 1).to(DEV), hd, torch.nn.Linear(1, 1).to(DEV))
+    real = O.det_fill('gp.real', (2, 3, 32, 32), 0.5, 0.5).to(DEV)
+    fake = O.det_fill('gp.fake', (2, 3, 32, 32), 0.5, 0.5).to(DEV)
+    gp = step.gradient_penalty(real, fake, torch.from_numpy(g['alpha']).to(DEV))
+    gp.backward()
+    assert abs(gp.item() - float(g['gp'])) < 1e-4
+    hp = dict(hd.named_parameters())
+    for k in ['model.0.weight', 'model.3.weight', 'model.3.bias', 'model.11.weight', 'model.17.fc2.weight',
+              'model.18.conv1.weight', 'model.25.weight']:
+        _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], 5e-3, msg=k)
+
+
+def test_train_two_iterations_small(golden):
+    worst, wdiff = train_parity(DEV, 'train_small', 2, 1, 2, 8, 4, 2, golden('train_small'))
+    assert worst < TOL and wdiff < 5e-3, (worst, wdiff)
+
+
+def test_train_two_iterations_full_size(golden):
+    """x4, 54->216, 12 groups x 3 RAB, B=2: losses/PSNR-relevant scalars within 1e-3 of the reference."""
+    worst, wdiff = train_parity(DEV, 'train_full', 12, 3, 2, 54, 4, 2, golden('train_full'))
+    assert worst < TOL, (worst, wdiff)
