@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- SRADSGAN x4 training images/sec on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training iteration of the reference's batch loop (SRADSGAN/model/sradsgan.py:
+829-892): G forward/backward (+VGG perceptual branch, +D), Adam(G), three D forwards, the WGAN-GP
+double backward, Adam(D), weight clip -- on a per-GPU batch of 32 synthetic 54x54 -> 216x216 tiles
+(BASELINE.json configs[2]; with N>1 ranks, configs[3]: weak scaling, global batch 32*N, RCCL
+all-reduce of G and D gradients).  Inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, fp32 MFMA) timed with HIP
+                  events on the launch stream: algorithmic FLOPs per launch / average duration;
+  cpu_baseline -- the CPU oracle (oracle/sradsgan_ref.py, a port of the reference step) timed on the
+                  host cores of this box on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 32
+SCALE, LR_SIDE = 4, 54
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GF_PER_IMG_ITER = 362.6                # algorithmic GFLOP per image per training iteration (x4)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch (default: BASELINE config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    return ap.parse_args()
+
+
+def build_networks(device, seed):
+    """Random-init networks of the reference architecture (weights_init_normal semantics,
+    utils/utils.py:97-114: conv W~N(0,.02), b=0; BN W~N(1,.02), b=0; attention gammas stay 0)."""
+    import torch
+    from sradsgan_amd import model as M
+    g = torch.Generator().manual_seed(seed)
+    G = M.GeneratorResNet(M.ResGroup, n_residual_blocks=12, n_basic_blocks=3, rla_mode='CA-SA', bla_mode='CA-SA',
+                          ga_mode='CA-SA', pool_mode='Avg|Max', upscale_factor=SCALE)
+    D, F = M.Discriminator(), M.FeatureExtractor()
+    with torch.no_grad():
+        for net in (G, D):
+            for m in net.modules():
+                name = m.__class__.__name__
+                if 'Conv2d' in name:
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.02)
+                    if m.bias is not None:
+                        m.bias.zero_()
+                elif 'BatchNorm' in name:
+                    m.weight.copy_(1.0 + torch.randn(m.weight.shape, generator=g) * 0.02)
+                    m.bias.zero_()
+        for m in F.modules():                    # VGG stand-in: He-scaled random weights (no pretrained file offline)
+            if 'Conv2d' in m.__class__.__name__:
+                fan_in = m.weight.shape[1] * 9
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                m.bias.zero_()
+    return G.to(device), D.to(device), F.to(device)
+
+
+def time_dominant_kernel(device, batch):
+    """HIP-event timing of the dominant kernel on the stream it is launched on: RAB conv1
+    (3x3, 64->256, +bias +LeakyReLU) at the bench shape [batch,64,54,54]."""
+    import torch
+    from sradsgan_amd import ops
+    x = torch.randn(batch, 64, LR_SIDE, LR_SIDE, device=device).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=device) * 0.02)
+    b = torch.randn(256, device=device) * 0.01
+    for _ in range(5):
+        ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
+    torch.cuda.synchronize()
+    iters = 50
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'igemm_fprop 3x3 64->256 @54x54 (RAB conv1)', 'achieved': round(achieved, 2),
+            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            'traffic': None, 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4), 'dtype_peak': 'f32 MFMA dense'}
+
+
+def cpu_baseline(iters):
+    """The oracle's train_step (a port of sradsgan.py:829-892 to stock torch CPU ops) on B=2 tiles."""
+    import torch
+    from oracle import sradsgan_ref as O
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    G = O.GeneratorResNet(O.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=SCALE)
+    D, F = O.Discriminator(), O.FeatureExtractor()
+    G.apply(O.weights_init_normal), D.apply(O.weights_init_normal)
+    oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    oD = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    lr = torch.rand(B, 3, LR_SIDE, LR_SIDE)
+    hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE)
+    alpha = torch.rand(B, 1, 1, 1)
+    O.train_step(G, D, F, oG, oD, lr, hr, alpha)              # warm-up (oneDNN primitive creation)
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        O.train_step(G, D, F, oG, oD, lr, hr, alpha)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(B / med, 4), 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'batch 2 x %d iterations (+1 warm-up) of the identical x4 54->216 training step, '
+                      'oracle/sradsgan_ref.train_step on torch CPU ops, median' % iters}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print('bench.py: WORLD_SIZE=%d but --gpus %d; launch with torch.distributed.run --nproc-per-node %d'
+              % (world, args.gpus, args.gpus), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
+    from sradsgan_amd import _hip
+    _hip.lib()                                               # fail loudly if the extension is missing
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from sradsgan_amd.train_step import TrainStep
+    from sradsgan_amd import dp
+    B = args.batch
+    G, D, F = build_networks(device, seed=20240)             # identical initial replicas on every rank
+    sync = dp.GradSync(world) if world > 1 else None
+    step = TrainStep(G, D, F, grad_sync=sync, use_graph=not args.no_graph)
+    gen = torch.Generator().manual_seed(1234 + rank)         # disjoint synthetic shards per rank
+    hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
+    lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
+    alpha = torch.rand(B, 1, 1, 1, generator=gen).to(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step(lr, hr, alpha)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(lr, hr, alpha)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = all(bool(torch.isfinite(out[k]).all()) for k in ('loss_G', 'loss_D'))
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        line = {
+            'metric': 'training images/sec (216x216, x4)', 'value': round(value, 3), 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SRADSGAN full GAN x4 training step (G+D+VGG perceptual, WGAN-GP), '
+                                   'LR 54x54 -> HR 216x216, per-GPU batch %d' % B,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                       'launch': 'eager' if args.no_graph else 'hipGraph'},
+            'losses_finite': finite,
+            'step_tflops': round(value * GF_PER_IMG_ITER / 1e3, 2),
+            'step_frac_of_f32_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+        }
+        line['roofline'] = time_dominant_kernel(device, B)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -86,6 +86,15 @@ int srhip_pixel_shuffle_fwd(const float* in, float* out, int n, int h, int w, in
 int srhip_pixel_shuffle_bwd(const float* dout, const float* out, float* din, int n, int h, int w,
                             int cout, int r, float slope, int apply_act, void* stream);
 
+/* ---- torch.optim.Adam (sradsgan.py:724-725, step at :858 and :887) over a flat fp32 arena, fused
+ *      with the discriminator's weight clip `p.data.clamp_(-c, c)` (:891-892; clip <= 0: none).
+ * p,g,m,v: [n] arenas (n % 4 == 0, 16-byte aligned); g is multiplied by grad_scale first (1/world
+ * for the data-parallel mean).  state: float[4] on the device {step, lr/(1-b1^step),
+ * sqrt(1-b2^step), -}; the call advances it on the device, so it is hipGraph-capturable.
+ * Arithmetic order follows torch.optim.Adam (eps added after sqrt(v)/sqrt(bias_correction2)).     */
+int srhip_adam_step(float* p, const float* g, float* m, float* v, float* state, long n, float lr, float b1,
+                    float b2, float eps, float grad_scale, float clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ SIGNATURES = {
     'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
     'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'srhip_adam_step': (_i, [_vp] * 5 + [_l] + [_f] * 6 + [_vp]),
 }
 
 _lib = None

@@ -1,33 +1,57 @@
 """One SRADSGAN training iteration on the HIP path: the body of the reference's batch loop
-(SRADSGAN/model/sradsgan.py:829-892) with identical arithmetic and update order.
+(SRADSGAN/model/sradsgan.py:829-892) with identical arithmetic.
+
+Structure (MI355X-first, not the reference's call order):
+  compute   = zero grads; G forward, losses, backward; D forwards, gradient penalty, backward.
+              Every kernel of it is launched on one HIP stream and -- with use_graph=True -- captured
+              once into a hipGraph and replayed per iteration (the step is ~7000 launches; replay
+              removes the host from the critical path).
+  exchange  = in-place bucketed all-reduce of the G and D gradient arenas over RCCL (only with
+              world_size > 1; sradsgan_amd/dp.py).
+  update    = one fused Adam kernel per network over its flat arena (srhip_adam_step), the D one
+              also applying the weight clip (:891-892).
 
 Differences from the reference that do not change results (DESIGN.md "restructured, same numbers"):
+  * Adam(G) runs after the D-step compute instead of before it: the D step reads only
+    gen_hr.detach() and D's weights, never G's, so the order is unobservable;
   * during the G step the discriminator / VGG parameters do not require grad, so the weight
     gradients the reference computes and then throws away (:857 -> :865) are never computed;
   * the gradient penalty's double backward runs once with weight (1 + lambda_gp) instead of twice
     (once inside gradient_penalty() :639, once inside loss_D.backward() :886) -- same sum;
   * losses stay on the device; nothing calls .item() inside the step (the reference syncs 4x, :898).
 """
+import ctypes
+
 import torch
 
-from . import ops
+from . import _hip, ops
+from .dp import ParamArena
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
 
 
 class TrainStep:
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
-                 grad_sync=None):
+                 grad_sync=None, use_graph=False):
         self.G, self.D, self.F = generator, discriminator, feature_extractor
         self.weight_content, self.weight_gan = weight_content, weight_gan
         self.lambda_gp, self.clip_value, self.use_gp = lambda_gp, clip_value, use_gp
-        self.opt_G = torch.optim.Adam(self.G.parameters(), lr=lr, betas=(b1, b2))      # sradsgan.py:724
-        self.opt_D = torch.optim.Adam(self.D.parameters(), lr=lr, betas=(b1, b2))      # sradsgan.py:725
-        self.grad_sync = grad_sync            # data-parallel hook: callable(list_of_params)
-        self._d_params = [p for p in self.D.parameters()]
-        self._g_params = [p for p in self.G.parameters()]
+        self.lr_G = self.lr_D = lr                       # sradsgan.py:724-725 (halved on plateau, :1021-1027)
+        self.b1, self.b2, self.eps = b1, b2, 1e-8
+        self.arena_G, self.arena_D = ParamArena(self.G), ParamArena(self.D)
+        self.grad_sync = grad_sync                       # dp.GradSync or None
+        self.use_graph = use_graph
+        self._graph = None
+        self._calls = 0
+        self._static = None
+        self._d_params = self.arena_D.params
         for p in self.F.parameters():
-            p.requires_grad_(False)           # never in an optimiser (sradsgan.py:724-725)
+            p.requires_grad_(False)                      # never in an optimiser (sradsgan.py:724-725)
 
+    # ------------------------------------------------------------------------------------------ #
     def _set_d_grad(self, flag):
         for p in self._d_params:
             p.requires_grad_(flag)
@@ -41,11 +65,11 @@ class TrainStep:
             (grads,) = torch.autograd.grad(d_out, interp, torch.ones_like(d_out), create_graph=True)
         return ops.gp_penalty(grads)
 
-    def __call__(self, imgs_lr, imgs_hr, alpha):
+    def _compute(self, imgs_lr, imgs_hr, alpha):
         G, D, F = self.G, self.D, self.F
-        # ------------------ generator (sradsgan.py:829-858) ------------------
+        # ------------------ generator (sradsgan.py:829-857) ------------------
         self._set_d_grad(False)
-        self.opt_G.zero_grad(set_to_none=True)
+        self.arena_G.zero_grad()
         gen_hr = G(imgs_lr)
         pixel = ops.l1_mean(gen_hr, imgs_hr)
         with torch.no_grad():
@@ -54,12 +78,9 @@ class TrainStep:
         loss_gan = -D(gen_hr).mean()
         loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
         loss_G.backward()
-        if self.grad_sync is not None:
-            self.grad_sync(self._g_params)
-        self.opt_G.step()
-        # ---------------- discriminator (sradsgan.py:865-892) ----------------
+        # ---------------- discriminator (sradsgan.py:865-886) ----------------
         self._set_d_grad(True)
-        self.opt_D.zero_grad(set_to_none=True)
+        self.arena_D.zero_grad()
         fake = gen_hr.detach()
         loss_D = -D(imgs_hr).mean() + D(fake).mean()
         if self.use_gp:
@@ -70,12 +91,56 @@ class TrainStep:
             gp = torch.zeros((), device=imgs_hr.device)
             total = loss_D
         total.backward()
-        if self.grad_sync is not None:
-            self.grad_sync(self._d_params)
-        self.opt_D.step()
-        with torch.no_grad():
-            torch._foreach_clamp_min_(self._d_params, -self.clip_value)                # :891-892
-            torch._foreach_clamp_max_(self._d_params, self.clip_value)
-        ops.bump_weight_epoch()
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+
+    def _adam(self, arena, lr, clip, scale):
+        _hip.check(_hip.lib().srhip_adam_step(_ptr(arena.flat_p), _ptr(arena.flat_g), _ptr(arena.exp_avg),
+                                              _ptr(arena.exp_avg_sq), _ptr(arena.step_state), arena.numel,
+                                              float(lr), float(self.b1), float(self.b2), float(self.eps),
+                                              float(scale), float(clip),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'adam_step')
+
+    def _update(self):
+        """exchange + update: sradsgan.py:858 (optimizer_G.step), :887 (optimizer_D.step), :891-892 (clip)."""
+        scale = 1.0
+        if self.grad_sync is not None and self.grad_sync.world > 1:
+            handles = self.grad_sync.start(self.arena_G.flat_g) + self.grad_sync.start(self.arena_D.flat_g)
+            self.grad_sync.finish(handles)
+            scale = self.grad_sync.grad_scale
+        self._adam(self.arena_G, self.lr_G, 0.0, scale)
+        self._adam(self.arena_D, self.lr_D, self.clip_value, scale)
+        ops.bump_weight_epoch()
+
+    # ------------------------------------------------------------------------------------------ #
+    def _capture(self, imgs_lr, imgs_hr, alpha):
+        self._static = dict(lr=imgs_lr.clone(), hr=imgs_hr.clone(), alpha=alpha.clone())
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
+
+    def __call__(self, imgs_lr, imgs_hr, alpha):
+        self._calls += 1
+        if not self.use_graph:
+            out = self._compute(imgs_lr, imgs_hr, alpha)
+            self._update()
+            return out
+        if self._calls == 1:
+            # first iteration runs eagerly on a side stream (library/allocator warm-up required before
+            # stream capture); it is a real iteration, not a discarded one
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = self._compute(imgs_lr, imgs_hr, alpha)
+                self._update()
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        if self._graph is None:
+            self._capture(imgs_lr, imgs_hr, alpha)           # records only; nothing executes
+        else:
+            for k, t in (('lr', imgs_lr), ('hr', imgs_hr), ('alpha', alpha)):
+                if t.data_ptr() != self._static[k].data_ptr():
+                    self._static[k].copy_(t)
+        self._graph.replay()
+        self._update()
+        return self._out

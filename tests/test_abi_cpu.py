@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/sradsgan_hip.h declares, the ctypes table covers them all, and the product path refuses to
+run without a HIP device (no CPU fallback).  No compute call is made here."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'sradsgan_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(srhip_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as ge
+    from sradsgan_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        ge.build()
+    return _hip.lib()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from sradsgan_amd import _hip
+    names = _declared()
+    assert len(names) >= 14
+    assert sorted(_hip.SIGNATURES) == names, 'ctypes table and header disagree'
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_pure_host_entry_points(lib):
+    assert lib.srhip_abi_version() >= 1
+    assert lib.srhip_packed_ld(64) == 64 and lib.srhip_packed_ld(3) == 32 and lib.srhip_packed_ld(65) == 96
+    assert lib.srhip_colsum_workspace(1000, 64) >= 64 * 4
+    assert lib.srhip_conv2d_wgrad_workspace(2, 54, 54, 64, 256, 3, 3, 1, 1) >= 256 * 576 * 4
+
+
+def test_argument_errors_do_not_cross_as_exceptions(lib):
+    rc = lib.srhip_conv2d_fwd(None, None, None, None, None, None, 1, 4, 4, 3, 3, 3, 3, 1, 1, 3, 3, 3, 0.0, 0, None)
+    assert rc == -1 and b'null tensor' in lib.srhip_last_error()
+    rc = lib.srhip_adam_step(None, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, None)
+    assert rc == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    from sradsgan_amd import ops
+    x = torch.zeros(1, 3, 4, 4)
+    w = torch.zeros(2, 3, 3, 3)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.conv2d(x, w, None, 1, 1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'sradsgan_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py') and f != 'smoke.py':        # smoke() uses the oracle as its checker only
+                assert 'oracle' not in open(os.path.join(dirpath, f)).read().replace('the CPU oracle', ''), f
+
+
+def test_param_arena_views_and_state_dict_roundtrip():
+    from sradsgan_amd.dp import ParamArena
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.BatchNorm2d(5), torch.nn.Conv2d(5, 2, 1))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    arena = ParamArena(net)
+    assert arena.check_views() and arena.numel % 64 == 0
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k])
+    net(torch.randn(2, 3, 8, 8)).sum().backward()
+    assert arena.check_views() and float(arena.flat_g.abs().sum()) > 0     # autograd accumulated in place
+    arena.zero_grad()
+    assert all(float(p.grad.abs().sum()) == 0 for p in net.parameters())
+    net.load_state_dict({k: v + 1 for k, v in before.items()})
+    assert arena.check_views()
+    o = arena.offsets[0]
+    assert torch.equal(arena.flat_p[o:o + 135].view(5, 3, 3, 3), before['0.weight'] + 1)
