@@ -39,8 +39,12 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch (default: BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the compute part from a captured hipGraph (experimental, see DESIGN.md section 6)')
+    ap.add_argument('--no-graph', action='store_true', help='(default) launch every kernel eagerly')
     ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
     return ap.parse_args()
 
 
@@ -98,12 +102,35 @@ def time_dominant_kernel(device, batch):
             'traffic': None, 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4), 'dtype_peak': 'f32 MFMA dense'}
 
 
-def cpu_baseline(iters):
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU
+    box runs us in a container; os.cpu_count() reports the whole host and oversubscribing it stalls)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(iters, budget_s=60.0):
     """The oracle's train_step (a port of sradsgan.py:829-892 to stock torch CPU ops) on B=2 tiles."""
     import torch
     from oracle import sradsgan_ref as O
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     B = 2
     G = O.GeneratorResNet(O.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=SCALE)
@@ -114,21 +141,44 @@ def cpu_baseline(iters):
     lr = torch.rand(B, 3, LR_SIDE, LR_SIDE)
     hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE)
     alpha = torch.rand(B, 1, 1, 1)
+    t_start = time.perf_counter()
     O.train_step(G, D, F, oG, oD, lr, hr, alpha)              # warm-up (oneDNN primitive creation)
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
         O.train_step(G, D, F, oG, oD, lr, hr, alpha)
         ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:          # bounded sample: never hold the bench for minutes
+            break
     ts.sort()
     med = ts[len(ts) // 2]
     return {'value': round(B / med, 4), 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': 'batch 2 x %d iterations (+1 warm-up) of the identical x4 54->216 training step, '
-                      'oracle/sradsgan_ref.train_step on torch CPU ops, median' % iters}
+                      'oracle/sradsgan_ref.train_step on torch CPU ops, median' % len(ts)}
+
+
+def cpu_baseline_subprocess(iters, timeout_s=240):
+    """Runs the CPU leg in a child process (own thread pool, hard wall-clock bound) and returns its dict."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--cpu-iters', str(iters)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {'value': None, 'unit': 'img/s', 'cores': usable_cores(), 'kind': 'port',
+                'sample': 'CPU leg failed: ' + (out.stderr.strip().splitlines() or ['no output'])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'img/s', 'cores': usable_cores(), 'kind': 'port',
+                'sample': 'CPU leg exceeded its %d s bound on this host' % timeout_s}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_iters)), flush=True)
+        return
     import torch
     import torch.distributed as dist
 
@@ -153,7 +203,8 @@ def main():
     B = args.batch
     G, D, F = build_networks(device, seed=20240)             # identical initial replicas on every rank
     sync = dp.GradSync(world) if world > 1 else None
-    step = TrainStep(G, D, F, grad_sync=sync, use_graph=not args.no_graph)
+    step = TrainStep(G, D, F, grad_sync=sync, use_graph=args.graph and not args.no_graph,
+                     use_gp=os.environ.get('BENCH_NO_GP') != '1')
     gen = torch.Generator().manual_seed(1234 + rank)         # disjoint synthetic shards per rank
     hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
     lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
@@ -164,19 +215,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = []
     for _ in range(args.warmup):
         out = step(lr, hr, alpha)
-    barrier()
+        if args.trace_losses:
+            trace.append({k: out[k].clone() for k in ('loss_G', 'loss_D')})
+        if os.environ.get('BENCH_SYNC_EACH') == '1':
+            torch.cuda.synchronize()
+    if os.environ.get('BENCH_NO_WARM_BARRIER') != '1':
+        barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(lr, hr, alpha)
+        if args.trace_losses:
+            trace.append({k: out[k].clone() for k in ('loss_G', 'loss_D')})
+        if os.environ.get('BENCH_SYNC_EACH') == '1':
+            torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    if trace:
+        print('losses per step:', ' '.join('%d:%.4g/%.4g' % (i, float(t['loss_G']), float(t['loss_D']))
+                                           for i, t in enumerate(trace)), file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    finite = all(bool(torch.isfinite(out[k]).all()) for k in ('loss_G', 'loss_D'))
+    losses = {k: float(out[k]) for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')}
+    finite = all(v == v and abs(v) != float('inf') for v in losses.values())
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -188,14 +253,14 @@ def main():
             'config': {'workload': 'SRADSGAN full GAN x4 training step (G+D+VGG perceptual, WGAN-GP), '
                                    'LR 54x54 -> HR 216x216, per-GPU batch %d' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if args.no_graph else 'hipGraph'},
-            'losses_finite': finite,
+                       'launch': 'hipGraph' if (args.graph and not args.no_graph) else 'eager'},
+            'losses_finite': finite, 'last_losses': {k: round(v, 6) for k, v in losses.items()},
             'step_tflops': round(value * GF_PER_IMG_ITER / 1e3, 2),
             'step_frac_of_f32_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
         }
         line['roofline'] = time_dominant_kernel(device, B)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_iters)
+            line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

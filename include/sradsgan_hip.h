@@ -33,16 +33,19 @@ extern "C" {
 #define SRHIP_EPI_LRELU 2     /* y = y > 0 ? y : slope*y   (slope 0 => ReLU)               */
 #define SRHIP_EPI_RESIDUAL 4  /* y += residual (after the activation): `out += x`          */
 #define SRHIP_EPI_ROWSCALE 8  /* y = rowscale[pixel] * (W.x) (+bias...) : SLAM mask folded */
+#define SRHIP_EPI_ACTMASK 32  /* (dgrad) y = actmask > 0 ? y : slope*y : backward of the producer's LeakyReLU */
+#define SRHIP_EPI_CHANSCALE 16 /* x[n,h,w,c] is read as x*chanscale[n][c] : CLAM scale folded (Cin%16==0) */
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
+/* experiment knobs for kernel tuning (key 0: fast-conv tile configuration, 0 = heuristic) */
+int srhip_debug_set(int key, int value);
 
 /* ---- weight packing ------------------------------------------------------------------------ *
- * OIHW parameter -> GEMM "B" operand [KH*KW*Csrc][ld], ld = srhip_packed_ld(Cdst) (zero padded).
- * mode 0 (fprop):  row (kh,kw,ci), col co        = w[co][ci][kh][kw]
- * mode 1 (dgrad):  row (kh,kw,co), col ci        = w[co][ci][KH-1-kh][KW-1-kw]
- * Runs once per optimiser step per conv (weights change every iteration).                      */
-int srhip_packed_ld(int cdst);
+ * OIHW parameter -> the GEMM "B" operand the conv kernels read.  mode 0 = fprop operand,
+ * mode 1 = dgrad operand.  The internal layout depends only on (cout,cin,kh,kw,mode); the buffer
+ * must hold srhip_packed_elems() floats.  Runs once per optimiser step per conv.                */
+size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode);
 int srhip_pack_weight(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw, int mode,
                       void* stream);
 
@@ -50,24 +53,31 @@ int srhip_pack_weight(const float* w_oihw, float* packed, int cout, int cin, int
  *      vgg19.features convs :92-95) with the elementwise tail of its call site fused:
  *      bias, LeakyReLU (:242,:337,:383,:428,:479) and the residual add (:274,:323).
  * x: [N,H,W,ldx>=Cin]  packed: srhip_pack_weight(mode 0)  y: [N,Ho,Wo,ldy>=Cout]
- * residual: [N,Ho,Wo,ldr] or NULL; rowscale: [N*Ho*Wo] or NULL.                                */
+ * residual: [N,Ho,Wo,ldr] or NULL; rowscale: [N*Ho*Wo] or NULL; chanscale: [N][Cin] or NULL.   */
 int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
-                     const float* rowscale, float* y, int n, int h, int w, int cin, int cout, int kh,
+                     const float* rowscale, const float* chanscale, float* y, int n, int h, int w, int cin, int cout, int kh,
                      int kw, int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags,
                      void* stream);
 
 /* ---- conv backward-data (autograd of the same call sites; second-order use in
  *      SRADSGAN.gradient_penalty :621,:639).  dy: [N,Ho,Wo,ldy] packed: mode 1  dx: [N,H,W,ldx].
+ * Optional fused tail (Cout % 16 == 0): actmask [N,H,W,ldx] = the OUTPUT of the LeakyReLU(slope) that
+ * produced this conv's input -- dx is multiplied by its derivative (backward of :242,:252 without a
+ * separate pass); residual [N,H,W,ldr] is added afterwards (gradient of the skip path, :274).
  * accumulate != 0 adds into dx (gradient fan-in of the dense bus :459).                        */
-int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, int h, int w, int cin,
-                       int cout, int kh, int kw, int stride, int pad, int ldy, int ldx, int accumulate,
-                       void* stream);
+int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,
+                       float slope, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
+                       int ldy, int ldx, int ldr, int accumulate, void* stream);
 
-/* ---- conv backward-weight: dw (OIHW) = sum over pixels of dy (x) window(x).  Deterministic
- *      two-pass split-K; `workspace` must hold srhip_conv2d_wgrad_workspace() bytes.           */
+/* ---- conv backward-weight: dw (OIHW) = sum over pixels of dy (x) window(x), and (db != NULL) the
+ *      bias gradient db[co] = sum over pixels of dy.  Deterministic two-pass split-K (no atomics);
+ *      `workspace` must hold srhip_conv2d_wgrad_workspace() bytes.  Optional xrowscale [N*H*W] /
+ *      xchanscale [N][Cin]: x is read as x * xrowscale[pixel] * xchanscale[n][c] (the un-materialised
+ *      input of the attention tail's 1x1 conv, sradsgan.py:262).                                  */
 size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
                                     int pad);
-int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, void* workspace,
+int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, const float* xrowscale,
+                       const float* xchanscale, void* workspace,
                        size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw,
                        int stride, int pad, int ldx, int ldy, void* stream);
 
@@ -85,6 +95,40 @@ int srhip_pixel_shuffle_fwd(const float* in, float* out, int n, int h, int w, in
                             float slope, int apply_act, void* stream);
 int srhip_pixel_shuffle_bwd(const float* dout, const float* out, float* din, int n, int h, int w,
                             int cout, int r, float slope, int apply_act, void* stream);
+
+/* ---- fused local-attention tail of RAB / ResGroup (sradsgan.py:254-274, 303-323; CLAM :117-127,
+ *      SLAM :141-151), C == 64.  u: [N,H,W,64] (conv2 output).  Forward produces the two scales
+ *      s[N][64] (CLAM) and m[N*H*W] (SLAM) plus what backward needs: avg/mx [N][64], argmax_hw [N][64]
+ *      (first max pixel per channel), pooled [N*H*W][2] (mean_c, max_c of s*u), argc [N*H*W] (first
+ *      max channel).  The caller then runs srhip_conv2d_fwd(u, ..., rowscale=m, chanscale=s,
+ *      residual=skip): y and z of the reference are never written to HBM.                         */
+size_t srhip_attn_tail_workspace(int n);
+int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, const float* w7, float* avg, float* mx,
+                        int* argmax_hw, float* s, float* pooled, int* argc, float* m, void* workspace,
+                        size_t workspace_bytes, int n, int h, int w, int c, int hidden, void* stream);
+/* backward, spatial half: dz = gradient at z (dgrad of the 1x1 conv).  Outputs du (partial: s * dy),
+ * ds [N][64] (gradient at s), dw7 [2*7*7].  The caller back-propagates ds through sigmoid + MLP
+ * (tiny, [N,64]) to davg/dmax and finishes with srhip_attn_tail_bwd_channel (in place on du).      */
+size_t srhip_attn_tail_bwd_workspace(int n, int h, int w);
+int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
+                                const int* argc, const float* w7, float* du, float* ds, float* dw7, void* workspace,
+                                size_t workspace_bytes, int n, int h, int w, int c, void* stream);
+int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
+                                int w, int c, void* stream);
+
+/* ---- train-mode nn.BatchNorm2d + LeakyReLU (discriminator, sradsgan.py:478-479), NHWC [rows][C].
+ * fwd: batch mean / biased variance -> y = act((x-mean)*invstd*gamma + beta); updates
+ * running_mean/var in place (momentum, unbiased variance) unless NULL; saves mean and invstd.
+ * bwd: dy is the gradient at y; the activation mask comes from y; produces dx, dgamma, dbeta.
+ * (The second-order pass needed by the gradient penalty :621,:639 is composed on the host side.)     */
+size_t srhip_bn_workspace(long rows, int c);
+int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
+                       size_t workspace_bytes, long rows, int c, float eps, float momentum, float slope, int apply_act,
+                       void* stream);
+int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, long rows, int c, float slope, int apply_act, void* stream);
 
 /* ---- torch.optim.Adam (sradsgan.py:724-725, step at :858 and :887) over a flat fp32 arena, fused
  *      with the discriminator's weight clip `p.data.clamp_(-c, c)` (:891-892; clip <= 0: none).

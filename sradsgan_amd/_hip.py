@@ -15,17 +15,26 @@ _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_l
 SIGNATURES = {
     'srhip_last_error': (ctypes.c_char_p, []),
     'srhip_abi_version': (_i, []),
-    'srhip_packed_ld': (_i, [_i]),
+    'srhip_debug_set': (_i, [_i, _i]),
+    'srhip_packed_elems': (_sz, [_i] * 5),
     'srhip_pack_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'srhip_conv2d_fwd': (_i, [_vp] * 6 + [_i] * 12 + [_f, _i, _vp]),
-    'srhip_conv2d_dgrad': (_i, [_vp] * 3 + [_i] * 12 + [_vp]),
+    'srhip_conv2d_fwd': (_i, [_vp] * 7 + [_i] * 12 + [_f, _i, _vp]),
+    'srhip_conv2d_dgrad': (_i, [_vp] * 5 + [_f] + [_i] * 13 + [_vp]),
     'srhip_conv2d_wgrad_workspace': (_sz, [_i] * 9),
-    'srhip_conv2d_wgrad': (_i, [_vp] * 4 + [_sz] + [_i] * 11 + [_vp]),
+    'srhip_conv2d_wgrad': (_i, [_vp] * 7 + [_sz] + [_i] * 11 + [_vp]),
     'srhip_colsum_workspace': (_sz, [_l, _i]),
     'srhip_colsum': (_i, [_vp, _vp, _vp, _sz, _l, _i, _i, _vp]),
     'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
     'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    'srhip_attn_tail_workspace': (_sz, [_i]),
+    'srhip_attn_tail_fwd': (_i, [_vp] * 12 + [_sz] + [_i] * 5 + [_vp]),
+    'srhip_attn_tail_bwd_workspace': (_sz, [_i] * 3),
+    'srhip_attn_tail_bwd_spatial': (_i, [_vp] * 11 + [_sz] + [_i] * 4 + [_vp]),
+    'srhip_attn_tail_bwd_channel': (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    'srhip_bn_workspace': (_sz, [_l, _i]),
+    'srhip_bn_train_fwd': (_i, [_vp] * 9 + [_sz, _l, _i, _f, _f, _f, _i, _vp]),
+    'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_adam_step': (_i, [_vp] * 5 + [_l] + [_f] * 6 + [_vp]),
 }
 

@@ -1,0 +1,417 @@
+// Fused local-attention tail of RAB / ResGroup (reference sradsgan.py:254-274, 303-323):
+//     y = CLAM(u) = s[b,c] * u            s = sigmoid(MLP(avgpool u) + MLP(maxpool u))   (:117-127)
+//     z = SLAM(y) = m[b,h,w] * y          m = sigmoid(conv7x7([mean_c y, max_c y]))       (:141-151)
+//     out = conv1x1(z) + bias + skip                                                      (:262,:274)
+// The reference runs ~15 elementwise/reduction launches and 5 extra HBM round trips per tail (x48 per
+// generator forward).  Here y and z are never materialised: the 1x1 conv consumes u with the two
+// scales folded into its A operand (per-image channel scale s) and its epilogue (per-pixel row scale
+// m); what is left are HBM-bound passes over u, each one 16-byte coalesced NHWC reads with 16 lanes
+// per pixel (4 channels per lane) and shuffle reductions inside the 16-lane group.
+// All kernels: C == 64 channels (the generator's width), ld == C, roofline = HBM bandwidth.
+#include "common.h"
+
+namespace srhip {
+
+constexpr int TC = 64;          // channels
+constexpr int SEG = 8;          // pooling segments per image
+
+__device__ inline float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+
+// ---- F1a: per (image, segment) partial avg-sum / max / first-argmax over pixels ------------------ //
+__global__ void clam_pool_partial_kernel(const float* __restrict__ u, float* __restrict__ psum,
+                                         float* __restrict__ pmax, int* __restrict__ parg, int hw) {
+  __shared__ float ssum[4][TC], smax[4][TC];
+  __shared__ int sarg[4][TC];
+  const int b = blockIdx.x / SEG, seg = blockIdx.x % SEG;
+  const int per = (hw + SEG - 1) / SEG;
+  const int p0 = seg * per, p1 = min(p0 + per, hw);
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;          // 4 row lanes x 64 channels
+  const float* base = u + (size_t)b * hw * TC + c;
+  float s = 0.f, mx = -INFINITY;
+  int am = 0x7fffffff;
+  for (int p = p0 + rl; p < p1; p += 4) {
+    const float v = base[(size_t)p * TC];
+    s += v;
+    if (v > mx) {
+      mx = v;
+      am = p;
+    }
+  }
+  ssum[rl][c] = s;
+  smax[rl][c] = mx;
+  sarg[rl][c] = am;
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      s += ssum[k][c];
+      const float v = smax[k][c];
+      const int a = sarg[k][c];
+      if (v > mx || (v == mx && a < am)) {
+        mx = v;
+        am = a;
+      }
+    }
+    const int o = (b * SEG + seg) * TC + c;
+    psum[o] = s;
+    pmax[o] = mx;
+    parg[o] = am;
+  }
+}
+
+// ---- F1b: combine segments, shared MLP 64 -> 4 -> 64 (no bias), sigmoid -> s[b,c] ---------------- //
+__global__ void clam_mlp_kernel(const float* __restrict__ psum, const float* __restrict__ pmax,
+                                const int* __restrict__ parg, const float* __restrict__ fc1,
+                                const float* __restrict__ fc2, float* __restrict__ avg, float* __restrict__ mx,
+                                int* __restrict__ arg, float* __restrict__ s, int hw, int hidden) {
+  __shared__ float sa[TC], sm[TC], ha[16], hm[16];
+  const int b = blockIdx.x, c = threadIdx.x;
+  float sum = 0.f, m = -INFINITY;
+  int am = 0x7fffffff;
+  for (int k = 0; k < SEG; ++k) {
+    const int o = (b * SEG + k) * TC + c;
+    sum += psum[o];
+    const float v = pmax[o];
+    const int a = parg[o];
+    if (v > m || (v == m && a < am)) {
+      m = v;
+      am = a;
+    }
+  }
+  const float a_ = sum / (float)hw;
+  avg[b * TC + c] = a_;
+  mx[b * TC + c] = m;
+  arg[b * TC + c] = am;
+  sa[c] = a_;
+  sm[c] = m;
+  __syncthreads();
+  if (c < hidden) {
+    float x0 = 0.f, x1 = 0.f;
+    for (int k = 0; k < TC; ++k) {
+      const float w = fc1[c * TC + k];
+      x0 += w * sa[k];
+      x1 += w * sm[k];
+    }
+    ha[c] = fmaxf(x0, 0.f);
+    hm[c] = fmaxf(x1, 0.f);
+  }
+  __syncthreads();
+  float l0 = 0.f, l1 = 0.f;
+  for (int j = 0; j < hidden; ++j) {
+    const float w = fc2[c * hidden + j];
+    l0 += w * ha[j];
+    l1 += w * hm[j];
+  }
+  const float l = l0 + l1;
+  s[b * TC + c] = 1.f / (1.f + expf(-l));
+}
+
+// ---- F2: pooled[pix] = (mean_c, max_c) of y = s*u, argc[pix] = first argmax channel -------------- //
+__global__ void slam_pool_kernel(const float* __restrict__ u, const float* __restrict__ s,
+                                 float2* __restrict__ pooled, int* __restrict__ argc, int hw, long npix) {
+  const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int cq = threadIdx.x & 15;
+  if (pix >= npix) return;
+  const int b = (int)(pix / hw);
+  const float4 v = *reinterpret_cast<const float4*>(u + pix * TC + cq * 4);
+  const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
+  const float y0 = v.x * sc.x, y1 = v.y * sc.y, y2 = v.z * sc.z, y3 = v.w * sc.w;
+  float sum = (y0 + y1) + (y2 + y3);
+  float mx = y0;
+  int am = cq * 4;
+  if (y1 > mx) { mx = y1; am = cq * 4 + 1; }
+  if (y2 > mx) { mx = y2; am = cq * 4 + 2; }
+  if (y3 > mx) { mx = y3; am = cq * 4 + 3; }
+  sum = group16_sum(sum);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 16);
+    const int oa = __shfl_xor(am, o, 16);
+    if (ov > mx || (ov == mx && oa < am)) {
+      mx = ov;
+      am = oa;
+    }
+  }
+  if (cq == 0) {
+    pooled[pix] = make_float2(sum / (float)TC, mx);
+    argc[pix] = am;
+  }
+}
+
+// ---- F3: m = sigmoid(conv7x7 pad 3 (2 -> 1, no bias)(pooled)) ------------------------------------- //
+__global__ void slam_conv7_kernel(const float2* __restrict__ pooled, const float* __restrict__ w7,
+                                  float* __restrict__ m, int h, int w, long npix) {
+  __shared__ float sw[98];
+  if (threadIdx.x < 98) sw[threadIdx.x] = w7[threadIdx.x];        // [ch][kh][kw]
+  __syncthreads();
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int hw = h * w;
+  const long b = pix / hw;
+  const int rem = (int)(pix - b * hw);
+  const int y = rem / w, x = rem - y * w;
+  const float2* img = pooled + b * hw;
+  float acc = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    const int yy = y + kh - 3;
+    if (yy < 0 || yy >= h) continue;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int xx = x + kw - 3;
+      if (xx < 0 || xx >= w) continue;
+      const float2 p = img[yy * w + xx];
+      acc += sw[kh * 7 + kw] * p.x;
+      acc += sw[49 + kh * 7 + kw] * p.y;
+    }
+  }
+  m[pix] = 1.f / (1.f + expf(-acc));
+}
+
+// ---- B1: da[pix] = (sum_c dz*s*u) * m*(1-m)  (gradient at the 7x7 conv's output) ------------------ //
+__global__ void tail_bwd_da_kernel(const float* __restrict__ dz, const float* __restrict__ u,
+                                   const float* __restrict__ s, const float* __restrict__ m,
+                                   float* __restrict__ da, int hw, long npix) {
+  const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int cq = threadIdx.x & 15;
+  if (pix >= npix) return;
+  const int b = (int)(pix / hw);
+  const float4 g = *reinterpret_cast<const float4*>(dz + pix * TC + cq * 4);
+  const float4 v = *reinterpret_cast<const float4*>(u + pix * TC + cq * 4);
+  const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
+  float d = (g.x * (v.x * sc.x) + g.y * (v.y * sc.y)) + (g.z * (v.z * sc.z) + g.w * (v.w * sc.w));
+  d = group16_sum(d);
+  if (cq == 0) {
+    const float mm = m[pix];
+    da[pix] = d * mm * (1.f - mm);
+  }
+}
+
+// ---- B2a: dpooled[pix][ch] = sum_{kh,kw} w7[ch][kh][kw] * da[(y-kh+3, x-kw+3)] --------------------- //
+__global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const float* __restrict__ w7,
+                                        float2* __restrict__ dpooled, int h, int w, long npix) {
+  __shared__ float sw[98];
+  if (threadIdx.x < 98) sw[threadIdx.x] = w7[threadIdx.x];
+  __syncthreads();
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int hw = h * w;
+  const long b = pix / hw;
+  const int rem = (int)(pix - b * hw);
+  const int y = rem / w, x = rem - y * w;
+  const float* img = da + b * hw;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+    const int yy = y - kh + 3;
+    if (yy < 0 || yy >= h) continue;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int xx = x - kw + 3;
+      if (xx < 0 || xx >= w) continue;
+      const float g = img[yy * w + xx];
+      a0 += sw[kh * 7 + kw] * g;
+      a1 += sw[49 + kh * 7 + kw] * g;
+    }
+  }
+  dpooled[pix] = make_float2(a0, a1);
+}
+
+// ---- B2b: dw7[ch][kh][kw] = sum_pix da[pix] * pooled[(y+kh-3, x+kw-3)][ch] ---------------------------- //
+// Every thread takes one pixel and all 98 taps (register accumulators), waves reduce with shuffles,
+// the block writes one 98-vector of partials; slam_conv7_wgrad_reduce_kernel sums the block partials.
+constexpr int W7_BLOCKS = 384;
+__global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __restrict__ da,
+                                                                const float2* __restrict__ pooled,
+                                                                float* __restrict__ part, int h, int w, long npix) {
+  __shared__ float red[4][98];
+  const int hw = h * w;
+  float acc[98];
+#pragma unroll
+  for (int t = 0; t < 98; ++t) acc[t] = 0.f;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+    const long b = pix / hw;
+    const int rem = (int)(pix - b * hw);
+    const int y = rem / w, x = rem - y * w;
+    const float g = da[pix];
+    const float2* img = pooled + b * hw;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+      const int yy = y + kh - 3;
+      const bool yok = yy >= 0 && yy < h;
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const int xx = x + kw - 3;
+        float2 p = make_float2(0.f, 0.f);
+        if (yok && xx >= 0 && xx < w) p = img[yy * w + xx];
+        acc[kh * 7 + kw] += g * p.x;
+        acc[49 + kh * 7 + kw] += g * p.y;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 98; ++t) {
+    const float v = wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 98)                              // tap-major partials: the reduce reads them contiguously
+    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw7, int nblk) {
+  const int t = blockIdx.x;                          // one wave per tap
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += 64) s += part[(size_t)t * nblk + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dw7[t] = s;
+}
+
+// ---- B3: dy = m*dz + dpooled.x/C + [c == argc]*dpooled.y ; du = s*dy ; ds partial = sum_pix dy*u --- //
+// grid = (blocks_per_image, B); each block walks pixels of ONE image; 256 threads = 16 pixel lanes x 16
+// channel quads; dsp[b][blk][c] holds the block's partial of ds.
+__global__ void tail_bwd_main_kernel(const float* __restrict__ dz, const float* __restrict__ u,
+                                     const float* __restrict__ s, const float* __restrict__ m,
+                                     const float2* __restrict__ dpooled, const int* __restrict__ argc,
+                                     float* __restrict__ du, float* __restrict__ dsp, int hw) {
+  __shared__ float4 red[256];
+  const int b = blockIdx.y, nblk = gridDim.x;
+  const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = blockIdx.x * 16 + pl; p < hw; p += nblk * 16) {
+    const long pix = (long)b * hw + p;
+    const float4 g = *reinterpret_cast<const float4*>(dz + pix * TC + cq * 4);
+    const float4 v = *reinterpret_cast<const float4*>(u + pix * TC + cq * 4);
+    const float mm = m[pix];
+    const float2 dp = dpooled[pix];
+    const int a = argc[pix] - cq * 4;
+    const float dmean = dp.x * (1.f / (float)TC);
+    float4 d;
+    d.x = mm * g.x + dmean + (a == 0 ? dp.y : 0.f);
+    d.y = mm * g.y + dmean + (a == 1 ? dp.y : 0.f);
+    d.z = mm * g.z + dmean + (a == 2 ? dp.y : 0.f);
+    d.w = mm * g.w + dmean + (a == 3 ? dp.y : 0.f);
+    acc.x += d.x * v.x;
+    acc.y += d.y * v.y;
+    acc.z += d.z * v.z;
+    acc.w += d.w * v.w;
+    *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = make_float4(sc.x * d.x, sc.y * d.y, sc.z * d.z, sc.w * d.w);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 o = red[k * 16 + cq];
+      acc.x += o.x;
+      acc.y += o.y;
+      acc.z += o.z;
+      acc.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dsp + ((size_t)b * nblk + blockIdx.x) * TC + cq * 4) = acc;
+  }
+}
+
+// ---- B4: ds[b,c] = sum over block partials --------------------------------------------------------- //
+__global__ void tail_bwd_ds_kernel(const float* __restrict__ dsp, float* __restrict__ ds, int nblk) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  float a = 0.f;
+  for (int k = 0; k < nblk; ++k) a += dsp[((size_t)b * nblk + k) * TC + c];
+  ds[b * TC + c] = a;
+}
+
+// ---- B5: du += davg[b,c]/HW + [pix == argmax_hw[b,c]] * dmax[b,c]  (in place) ----------------------- //
+__global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restrict__ davg,
+                                    const float* __restrict__ dmax, const int* __restrict__ arg, int hw, long npix) {
+  const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int cq = threadIdx.x & 15;
+  if (pix >= npix) return;
+  const int b = (int)(pix / hw);
+  const int p = (int)(pix - (long)b * hw);
+  const float inv = 1.f / (float)hw;
+  const float4 ga = *reinterpret_cast<const float4*>(davg + b * TC + cq * 4);
+  const float4 gm = *reinterpret_cast<const float4*>(dmax + b * TC + cq * 4);
+  const int4 am = *reinterpret_cast<const int4*>(arg + b * TC + cq * 4);
+  float4 d = *reinterpret_cast<float4*>(du + pix * TC + cq * 4);
+  d.x += ga.x * inv + (am.x == p ? gm.x : 0.f);
+  d.y += ga.y * inv + (am.y == p ? gm.y : 0.f);
+  d.z += ga.z * inv + (am.z == p ? gm.z : 0.f);
+  d.w += ga.w * inv + (am.w == p ? gm.w : 0.f);
+  *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = d;
+}
+
+constexpr int TAIL_BLK = 16;     // blocks per image in tail_bwd_main
+
+}  // namespace srhip
+
+using namespace srhip;
+
+extern "C" {
+
+size_t srhip_attn_tail_workspace(int n) { return (size_t)n * (SEG > TAIL_BLK ? SEG : TAIL_BLK) * TC * 3 * sizeof(float); }
+
+int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, const float* w7, float* avg, float* mx,
+                        int* argmax_hw, float* s, float* pooled, int* argc, float* m, void* workspace,
+                        size_t workspace_bytes, int n, int h, int w, int c, int hidden, void* stream) {
+  SRHIP_REQUIRE(u && fc1 && fc2 && w7 && avg && mx && argmax_hw && s && pooled && argc && m, "attn_tail_fwd: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_fwd: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_workspace(n), "attn_tail_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int hw = h * w;
+  const long npix = (long)n * hw;
+  float* psum = static_cast<float*>(workspace);
+  float* pmax = psum + (size_t)n * SEG * TC;
+  int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
+  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, hw);
+  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(TC), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden);
+  hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
+  hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
+  return check_launch("attn_tail_fwd");
+}
+
+size_t srhip_attn_tail_bwd_workspace(int n, int h, int w) {
+  return ((size_t)n * h * w * 3 + (size_t)n * TAIL_BLK * TC + (size_t)W7_BLOCKS * 98) * sizeof(float);
+}
+
+int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
+                                const int* argc, const float* w7, float* du, float* ds, float* dw7, void* workspace,
+                                size_t workspace_bytes, int n, int h, int w, int c, void* stream) {
+  SRHIP_REQUIRE(dz && u && s && m && pooled && argc && w7 && du && ds && dw7, "attn_tail_bwd_spatial: null tensor");
+  SRHIP_REQUIRE(c == TC && n > 0 && h > 0 && w > 0, "attn_tail_bwd_spatial: C must be 64");
+  const int hw = h * w;
+  const long npix = (long)n * hw;
+  const size_t need = srhip_attn_tail_bwd_workspace(n, h, w);
+  SRHIP_REQUIRE(workspace && workspace_bytes >= need, "attn_tail_bwd_spatial: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* da = static_cast<float*>(workspace);
+  float2* dpooled = reinterpret_cast<float2*>(da + npix);
+  float* dsp = da + 3 * npix;
+  float* w7part = dsp + (size_t)n * TAIL_BLK * TC;
+  hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
+  hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
+  const int w7blk = (int)(cdiv(npix, 256) < W7_BLOCKS ? cdiv(npix, 256) : W7_BLOCKS);
+  hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), 0, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, npix);
+  hipLaunchKernelGGL(slam_conv7_wgrad_reduce_kernel, dim3(98), dim3(64), 0, st, w7part, dw7, w7blk);
+  hipLaunchKernelGGL(tail_bwd_main_kernel, dim3(TAIL_BLK, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw);
+  hipLaunchKernelGGL(tail_bwd_ds_kernel, dim3(n), dim3(TC), 0, st, dsp, ds, TAIL_BLK);
+  return check_launch("attn_tail_bwd_spatial");
+}
+
+
+
+int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
+                                int w, int c, void* stream) {
+  SRHIP_REQUIRE(du && davg && dmax && argmax_hw && c == TC && n > 0 && h > 0 && w > 0, "attn_tail_bwd_channel: bad argument");
+  const int hw = h * w;
+  const long npix = (long)n * hw;
+  hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, as_stream(stream), du, davg, dmax, argmax_hw, hw, npix);
+  return check_launch("attn_tail_bwd_channel");
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// Train-mode BatchNorm2d (+ the LeakyReLU that follows it) of the discriminator, NHWC
+// (reference sradsgan.py:478-479; nn.BatchNorm2d: biased variance for normalisation, unbiased for
+// running_var, momentum 0.1, eps 1e-5).  HBM-bound: forward = 2 reads + 1 write of the tensor,
+// backward = 5 reads + 1 write (dy, x, y twice; x-hat is recomputed, never stored).
+// Statistics are reduced in two deterministic stages (<= 1024 row slabs, then per-column); sums are
+// taken about a per-channel shift (the first row) so E[d^2] - E[d]^2 does not cancel.
+#include "common.h"
+
+namespace srhip {
+
+__device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---- stage 1 of every per-channel reduction: MODE 0: (sum d, sum d^2), d = x - shift
+//                                              MODE 1: (sum dz, sum dz*xhat), dz = dy * lrelu'(y)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict__ a, const float* __restrict__ x,
+                                                        const float* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ partial,
+                                                        long rows, int c, long rows_per_block, float slope, int act) {
+  __shared__ float4 red0[256], red1[256];
+  const int tid = threadIdx.x;
+  const int q = c / 4, nrl = 256 / q;
+  const int cq = tid % q, rl = tid / q;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  float4 p0, p1;
+  if (MODE == 0) {
+    p0 = *reinterpret_cast<const float4*>(x + cq * 4);                     // shift = first row
+  } else {
+    p0 = *reinterpret_cast<const float4*>(mean + cq * 4);
+    p1 = *reinterpret_cast<const float4*>(invstd + cq * 4);
+  }
+  if (rl < nrl)
+    for (long r = r0 + rl; r < r1; r += nrl) {
+      const size_t o = (size_t)r * c + cq * 4;
+      if (MODE == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        const float4 d = make_float4(v.x - p0.x, v.y - p0.y, v.z - p0.z, v.w - p0.w);
+        s0 = f4add(s0, d);
+        s1 = f4add(s1, make_float4(d.x * d.x, d.y * d.y, d.z * d.z, d.w * d.w));
+      } else {
+        float4 g = *reinterpret_cast<const float4*>(a + o);
+        const float4 v = *reinterpret_cast<const float4*>(x + o);
+        if (act) {
+          const float4 yy = *reinterpret_cast<const float4*>(y + o);
+          g.x = yy.x > 0.f ? g.x : g.x * slope;
+          g.y = yy.y > 0.f ? g.y : g.y * slope;
+          g.z = yy.z > 0.f ? g.z : g.z * slope;
+          g.w = yy.w > 0.f ? g.w : g.w * slope;
+        }
+        s0 = f4add(s0, g);
+        s1 = f4add(s1, make_float4(g.x * ((v.x - p0.x) * p1.x), g.y * ((v.y - p0.y) * p1.y),
+                                   g.z * ((v.z - p0.z) * p1.z), g.w * ((v.w - p0.w) * p1.w)));
+      }
+    }
+  red0[tid] = s0;
+  red1[tid] = s1;
+  __syncthreads();
+  if (tid < q) {
+    for (int k = 1; k < nrl; ++k) {
+      s0 = f4add(s0, red0[k * q + tid]);
+      s1 = f4add(s1, red1[k * q + tid]);
+    }
+    float* o = partial + (size_t)blockIdx.x * 2 * c;
+    *reinterpret_cast<float4*>(o + tid * 4) = s0;
+    *reinterpret_cast<float4*>(o + c + tid * 4) = s1;
+  }
+}
+
+// stage 2 (forward): per channel mean / invstd, running statistics
+__global__ void bn_stats_stage2(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+                                float* __restrict__ invstd, float* __restrict__ running_mean,
+                                float* __restrict__ running_var, int nblk, int c, long rows, float eps,
+                                float momentum) {
+  __shared__ float r0[256], r1[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  float a = 0.f, b = 0.f;
+  if (col < c)
+    for (int k = sub; k < nblk; k += 4) {
+      a += partial[(size_t)k * 2 * c + col];
+      b += partial[(size_t)k * 2 * c + c + col];
+    }
+  r0[threadIdx.x] = a;
+  r1[threadIdx.x] = b;
+  __syncthreads();
+  if (sub == 0 && col < c) {
+    const int t = threadIdx.x;
+    const float s1 = (r0[t] + r0[t + 64]) + (r0[t + 128] + r0[t + 192]);
+    const float s2 = (r1[t] + r1[t + 64]) + (r1[t + 128] + r1[t + 192]);
+    const float n = (float)rows;
+    const float md = s1 / n;
+    float var = s2 / n - md * md;
+    var = var > 0.f ? var : 0.f;
+    const float mu = x[col] + md;
+    mean[col] = mu;
+    invstd[col] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mu;
+      const float unb = rows > 1 ? var * (n / (n - 1.f)) : var;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * unb;
+    }
+  }
+}
+
+// stage 2 (backward): dbeta = sum dz, dgamma = sum dz*xhat
+__global__ void bn_bwd_stage2(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                              int nblk, int c) {
+  __shared__ float r0[256], r1[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  float a = 0.f, b = 0.f;
+  if (col < c)
+    for (int k = sub; k < nblk; k += 4) {
+      a += partial[(size_t)k * 2 * c + col];
+      b += partial[(size_t)k * 2 * c + c + col];
+    }
+  r0[threadIdx.x] = a;
+  r1[threadIdx.x] = b;
+  __syncthreads();
+  if (sub == 0 && col < c) {
+    const int t = threadIdx.x;
+    dbeta[col] = (r0[t] + r0[t + 64]) + (r0[t + 128] + r0[t + 192]);
+    dgamma[col] = (r1[t] + r1[t + 64]) + (r1[t + 128] + r1[t + 192]);
+  }
+}
+
+// y = act((x - mean) * (invstd*gamma) + beta)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, long n4, int c, float slope,
+                                int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const int ch = (int)((i * 4) % c);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+    const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+    float4 o;
+    o.x = (v.x - mu.x) * is.x * ga.x + be.x;
+    o.y = (v.y - mu.y) * is.y * ga.y + be.y;
+    o.z = (v.z - mu.z) * is.z * ga.z + be.z;
+    o.w = (v.w - mu.w) * is.w * ga.w + be.w;
+    if (act) {
+      o.x = o.x > 0.f ? o.x : o.x * slope;
+      o.y = o.y > 0.f ? o.y : o.y * slope;
+      o.z = o.z > 0.f ? o.z : o.z * slope;
+      o.w = o.w > 0.f ? o.w : o.w * slope;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// dx = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    float* __restrict__ dx, long n4, int c, float inv_n, float slope, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const int ch = (int)((i * 4) % c);
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (act) {
+      const float4 yy = reinterpret_cast<const float4*>(y)[i];
+      g.x = yy.x > 0.f ? g.x : g.x * slope;
+      g.y = yy.y > 0.f ? g.y : g.y * slope;
+      g.z = yy.z > 0.f ? g.z : g.z * slope;
+      g.w = yy.w > 0.f ? g.w : g.w * slope;
+    }
+    const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+    const float4 dg = *reinterpret_cast<const float4*>(dgamma + ch);
+    const float4 db = *reinterpret_cast<const float4*>(dbeta + ch);
+    float4 o;
+    o.x = ga.x * is.x * (g.x - db.x * inv_n - (v.x - mu.x) * is.x * (dg.x * inv_n));
+    o.y = ga.y * is.y * (g.y - db.y * inv_n - (v.y - mu.y) * is.y * (dg.y * inv_n));
+    o.z = ga.z * is.z * (g.z - db.z * inv_n - (v.z - mu.z) * is.z * (dg.z * inv_n));
+    o.w = ga.w * is.w * (g.w - db.w * inv_n - (v.w - mu.w) * is.w * (dg.w * inv_n));
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+}
+
+static long bn_nblk(long rows) {
+  long nblk = (rows + 63) / 64;
+  return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);
+}
+
+}  // namespace srhip
+
+using namespace srhip;
+
+extern "C" {
+
+size_t srhip_bn_workspace(long rows, int c) { return (size_t)bn_nblk(rows) * 2 * c * sizeof(float); }
+
+int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
+                       size_t workspace_bytes, long rows, int c, float eps, float momentum, float slope, int apply_act,
+                       void* stream) {
+  SRHIP_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "bn_train_fwd: null tensor");
+  SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_fwd: C must be a multiple of 4, <= 1024");
+  SRHIP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats come in pairs");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_bn_workspace(rows, c), "bn_train_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const long nblk = bn_nblk(rows), rpb = (rows + nblk - 1) / nblk;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3((int)nblk), dim3(256), 0, st, nullptr, x, nullptr, nullptr, nullptr, part,
+                     rows, c, rpb, 0.f, 0);
+  hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, part, x, save_mean, save_invstd, running_mean,
+                     running_var, (int)nblk, c, rows, eps, momentum);
+  const long n4 = rows * c / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, n4, c,
+                     slope, apply_act);
+  return check_launch("bn_train_fwd");
+}
+
+int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                       const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, long rows, int c, float slope, int apply_act, void* stream) {
+  SRHIP_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && (y || !apply_act),
+                "bn_train_bwd: null tensor");
+  SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_bwd: C must be a multiple of 4, <= 1024");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_bn_workspace(rows, c), "bn_train_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const long nblk = bn_nblk(rows), rpb = (rows + nblk - 1) / nblk;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3((int)nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, part, rows,
+                     c, rpb, slope, apply_act);
+  hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, part, dgamma, dbeta, (int)nblk, c);
+  const long n4 = rows * c / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, gamma, dgamma,
+                     dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act);
+  return check_launch("bn_train_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// C-ABI entry points of the convolution family (include/sradsgan_hip.h): argument checking and the
+// choice between the fast kernels (conv_fast.hip) and the generic implicit-GEMM (conv_igemm.hip).
+// The choice depends only on the conv's static shape, so srhip_pack_weight and srhip_conv2d_* agree.
+#include "conv_internal.h"
+
+using namespace srhip;
+
+namespace srhip {
+extern int g_fast_cfg;
+extern int g_wgrad_cfg;
+}
+
+extern "C" {
+
+/* tuning/experiment knobs; key 0 = fast conv tile configuration (0 = built-in heuristic) */
+int srhip_debug_set(int key, int value) {
+  if (key == 0) {
+    g_fast_cfg = value;
+    return SRHIP_OK;
+  }
+  if (key == 1) {
+    g_wgrad_cfg = value;
+    return SRHIP_OK;
+  }
+  return SRHIP_ERR_ARG;
+}
+
+size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode) {
+  if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return 0;
+  const bool fast = mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw);
+  if (fast) return (size_t)cout * cin * kh * kw;
+  const int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
+  return (size_t)kh * kw * csrc * legacy_packed_ld(cdst);
+}
+
+int srhip_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, void* stream) {
+  SRHIP_REQUIRE(w && packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1),
+                "pack_weight: bad argument");
+  const bool fast = mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw);
+  if (fast) return fast_pack_weight(w, packed, cout, cin, kh, kw, mode, as_stream(stream));
+  return legacy_pack_weight(w, packed, cout, cin, kh, kw, mode, stream);
+}
+
+int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+                     const float* rowscale, const float* chanscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,
+                     int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, void* stream) {
+  SRHIP_REQUIRE(x && packed && y, "conv2d_fwd: null tensor");
+  SRHIP_REQUIRE(n >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_fwd: bad geometry");
+  SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_fwd: row stride smaller than channel count");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_BIAS) || bias, "conv2d_fwd: EPI_BIAS without bias");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_RESIDUAL) || (residual && ldr >= cout), "conv2d_fwd: EPI_RESIDUAL without residual");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_ROWSCALE) || rowscale, "conv2d_fwd: EPI_ROWSCALE without rowscale");
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_CHANSCALE) || chanscale, "conv2d_fwd: EPI_CHANSCALE without chanscale");
+  if (fast_fwd_ok(cin, cout, kh, kw))
+    return fast_conv2d_fwd(x, packed, bias, residual, rowscale, chanscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
+                           ldr, slope, flags, as_stream(stream));
+  SRHIP_REQUIRE(!(flags & SRHIP_EPI_CHANSCALE), "conv2d_fwd: EPI_CHANSCALE needs Cin % 16 == 0");
+  return legacy_conv2d_fwd(x, packed, bias, residual, rowscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
+                           ldr, slope, flags, stream);
+}
+
+int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,
+                       float slope, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
+                       int ldy, int ldx, int ldr, int accumulate, void* stream) {
+  SRHIP_REQUIRE(dy && packed && dx, "conv2d_dgrad: null tensor");
+  SRHIP_REQUIRE(n >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_dgrad: bad geometry");
+  SRHIP_REQUIRE(pad <= kh - 1 && pad <= kw - 1, "conv2d_dgrad: pad > kernel-1 unsupported");
+  SRHIP_REQUIRE(ldy >= cout && ldx >= cin, "conv2d_dgrad: row stride smaller than channel count");
+  SRHIP_REQUIRE(!residual || ldr >= cin, "conv2d_dgrad: residual row stride smaller than channel count");
+  if (fast_dgrad_ok(cin, cout, kh, kw))
+    return fast_conv2d_dgrad(dy, packed, dx, residual, actmask, slope, n, h, w, cin, cout, kh, kw, stride, pad, ldy,
+                             ldx, ldr, accumulate, as_stream(stream));
+  SRHIP_REQUIRE(!residual && !actmask, "conv2d_dgrad: fused residual/activation mask needs Cout % 16 == 0");
+  return legacy_conv2d_dgrad(dy, packed, dx, n, h, w, cin, cout, kh, kw, stride, pad, ldy, ldx, accumulate, stream);
+}
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0) return 0;
+  if (fast_wgrad_ok(cin, cout, kh, kw)) return fast_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
+  const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  const long rows = (long)n * ho * wo;
+  return align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad)) +
+         (rows > 0 ? colsum_workspace_bytes(rows, cout) : 0);
+}
+
+int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrowscale,
+                       const float* xchanscale, void* workspace,
+                       size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                       int pad, int ldx, int ldy, void* stream) {
+  SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
+                "conv2d_wgrad: bad geometry");
+  SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_wgrad: row stride smaller than channel count");
+  if (fast_wgrad_ok(cin, cout, kh, kw))
+    return fast_conv2d_wgrad(x, dy, dw, db, xrowscale, xchanscale, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx,
+                             ldy, as_stream(stream));
+  SRHIP_REQUIRE(!xrowscale && !xchanscale, "conv2d_wgrad: x scaling needs Cin % 64 == 0 and Cout % 4 == 0");
+  const size_t need = srhip_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
+  if (!workspace || workspace_bytes < need) {
+    set_error("conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return SRHIP_ERR_WORKSPACE;
+  }
+  const size_t wbytes = align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad));
+  int rc = legacy_conv2d_wgrad(x, dy, dw, workspace, wbytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy, stream);
+  if (rc || !db) return rc;
+  const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(cout % 4 == 0 ? cout <= 1024 : cout <= 256, "conv2d_wgrad: too many output channels for the bias sum");
+  return colsum_launch(dy, db, static_cast<char*>(workspace) + wbytes, (long)n * ho * wo, cout, ldy, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,716 @@
+// Fast implicit-GEMM convolution kernels for gfx950 (source channels % 16 == 0, <= 32 taps): the
+// shapes that carry >95 % of the SRADSGAN step's FLOPs (RAB 3x3 64<->256, 1x1 tails, upsampler,
+// discriminator and VGG 3x3 convs).  Exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// What makes them fast compared with the generic kernel (conv_igemm.hip):
+//   * both GEMM operands are "row = M/N index, K contiguous" in global memory (NHWC activations,
+//     n-major packed weights), so tiles go global -> VGPR -> LDS as 16-byte vectors with NO
+//     transpose, and MFMA fragments come back as ds_read_b128: the K order inside an 8-wide group is
+//     permuted identically for A and B (lanes 0-31 take k 0..3, lanes 32-63 take k 4..7), which a
+//     contraction does not care about.  LDS rows are 80 bytes apart => conflict-free b128 reads;
+//   * a K chunk of 16 never straddles a filter tap, so the im2col address of a chunk is
+//     "per-thread pixel base + one scalar tap offset"; padding/stride holes are handled by the
+//     buffer-load bounds check (offset >= num_records returns 0): no branches, ~3 VALU per load;
+//   * strided backward-data is decomposed into stride^2 phase classes, each a dense GEMM over only
+//     the taps that hit it (a 3x3 stride-2 dgrad does 9 tap-GEMMs instead of 36);
+//   * XCD-aware tile order: each of the 8 XCDs walks a contiguous range of output tiles, so the
+//     halo rows and the weights of neighbouring tiles are served by that XCD's L2;
+//   * wgrad also emits the bias gradient (column sums of dy) from the tiles it already stages.
+#include "conv_internal.h"
+
+namespace srhip {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FBK = 16;            // K values per chunk
+constexpr int FLS = FBK + 4;       // LDS row stride in floats (80 B: b128 reads hit all 64 banks once)
+constexpr unsigned F_OOB = 0x80000000u;
+
+struct FastGeom {
+  int N, Hs, Ws, C, lds;           // source tensor, NHWC, row stride lds (elements)
+  int OH, OW, M;                   // virtual output grid, M = N*OH*OW
+  int ss;                          // source pixel = (oh*ss + dh, ow*ss + dw)
+  int TH, TW, dh0, dhs, dw0, dws;  // tap grid: dh = dh0 + th*dhs, dw = dw0 + tw*dws
+  int kh0, khs, kw0, kws, KW;      // weight tap = (kh0 + th*khs)*KW + (kw0 + tw*kws)
+  int Hd, Wd, dsd, ph, pw, ldd, K; // destination pixel = (n, oh*dsd + ph, ow*dsd + pw), K channels
+  int ldw, ldr;
+  float slope;
+  int flags, accumulate, dst_identity;
+  unsigned src_bytes, w_bytes;
+};
+
+__device__ inline float4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return __builtin_bit_cast(float4, v);
+}
+
+__device__ inline f32x16 mfma32f(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// bijective "XCD b%8 gets a contiguous tile range" remap
+__device__ inline int xcd_tile(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// ================================================================================================ //
+// fprop / dgrad
+// ================================================================================================ //
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __restrict__ src,
+                                                                 const float* __restrict__ wt,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ residual,
+                                                                 const float* __restrict__ rowscale,
+                                                                 const float* __restrict__ chanscale,
+                                                                 const float* __restrict__ actmask,
+                                                                 float* __restrict__ dst, FastGeom g, int nblk_m,
+                                                                 int nblk_n) {
+  constexpr int NT = WM * WN * 64;                 // threads
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LS = BK + 4;                       // LDS row stride (floats): (LS/4) odd => conflict-free b128 reads
+  constexpr int QPR = BK / 4;                      // 16-byte quads per row
+  constexpr int RPP = NT / QPR;                    // rows covered by one pass of all threads
+  constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;
+  constexpr int STAGE = (BM + BN) * LS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
+  const int tile_n = tile % nblk_n, tile_m = tile / nblk_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lrow = tid / QPR, kq = tid % QPR;
+
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
+
+  // ---- per-thread row bookkeeping, fixed for the whole K loop ----
+  int abase[AR], aimg[AR];
+  unsigned amask[AR];
+  const int OHOW = g.OH * g.OW;
+  const bool cscale = (g.flags & SRHIP_EPI_CHANSCALE) != 0;      // A[m][k] *= chanscale[image(m)][c(k)]
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = m0 + lrow + RPP * i;
+    abase[i] = 0;
+    amask[i] = 0;
+    aimg[i] = 0;
+    if (m < g.M && (BM % RPP == 0 || lrow + RPP * i < BM)) {
+      const int n = m / OHOW;
+      aimg[i] = n;
+      const int rem = m - n * OHOW;
+      const int oh = rem / g.OW;
+      const int ow = rem - oh * g.OW;
+      const int sh0 = oh * g.ss, sw0 = ow * g.ss;
+      abase[i] = ((n * g.Hs + sh0) * g.Ws + sw0) * g.lds + kq * 4;
+      unsigned mk = 0;
+      for (int th = 0; th < g.TH; ++th) {
+        const int sh = sh0 + g.dh0 + th * g.dhs;
+        for (int tw = 0; tw < g.TW; ++tw) {
+          const int sw = sw0 + g.dw0 + tw * g.dws;
+          if (sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws) mk |= 1u << (th * g.TW + tw);
+        }
+      }
+      amask[i] = mk;
+    }
+  }
+  int bbase[BR];
+  bool bval[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int n = n0 + lrow + RPP * j;
+    bval[j] = (BN % RPP == 0 || lrow + RPP * j < BN) && n < g.K;
+    bbase[j] = n * g.ldw + kq * 4;
+  }
+
+  // ---- K-loop state (wave-uniform): tap (th,tw), channel chunk cc ----
+  const int CC = g.C / BK;
+  const int nk = g.TH * g.TW * CC;
+  int th = 0, tw = 0, cc = 0;
+  float4 ra[AR], rb[BR], rsc[AR];
+
+  auto load_tiles = [&]() {
+    const int tapoff = ((g.dh0 + th * g.dhs) * g.Ws + (g.dw0 + tw * g.dws)) * g.lds + cc * BK;
+    if (cscale) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        rsc[i] = *reinterpret_cast<const float4*>(chanscale + (size_t)aimg[i] * g.C + cc * BK + kq * 4);
+    }
+    const int wk = ((g.kh0 + th * g.khs) * g.KW + (g.kw0 + tw * g.kws)) * g.C + cc * BK;
+    const int bit = th * g.TW + tw;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const unsigned off = ((amask[i] >> bit) & 1u) ? (unsigned)(abase[i] + tapoff) * 4u : F_OOB;
+      ra[i] = bufload4(rs, off);
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const unsigned off = bval[j] ? (unsigned)(bbase[j] + wk) * 4u : F_OOB;
+      rb[j] = bufload4(rw, off);
+    }
+    if (++cc == CC) {
+      cc = 0;
+      if (++tw == g.TW) {
+        tw = 0;
+        ++th;
+      }
+    }
+  };
+  auto store_tiles = [&](int stage) {
+    float* a = lds + stage * STAGE + lrow * LS + kq * 4;
+    if (cscale) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        ra[i].x *= rsc[i].x;
+        ra[i].y *= rsc[i].y;
+        ra[i].z *= rsc[i].z;
+        ra[i].w *= rsc[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      if (BM % RPP == 0 || lrow + RPP * i < BM) *reinterpret_cast<float4*>(a + RPP * i * LS) = ra[i];
+    float* b = lds + stage * STAGE + BM * LS + lrow * LS + kq * 4;
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      if (BN % RPP == 0 || lrow + RPP * j < BN) *reinterpret_cast<float4*>(b + RPP * j * LS) = rb[j];
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int khalf = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  if (nk > 0) {
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+      const int stage = kc & 1;
+      if (kc + 1 < nk) load_tiles();
+      const float* a = lds + stage * STAGE + (wm * WTM + l31) * LS + khalf * 4;
+      const float* b = lds + stage * STAGE + BM * LS + (wn * WTN + l31) * LS + khalf * 4;
+      float4 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) af[0][t] = *reinterpret_cast<const float4*>(a + t * 32 * LS);
+#pragma unroll
+      for (int u = 0; u < TN; ++u) bf[0][u] = *reinterpret_cast<const float4*>(b + u * 32 * LS);
+#pragma unroll
+      for (int ks = 0; ks < BK / 8; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < BK / 8) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) af[nxt][t] = *reinterpret_cast<const float4*>(a + t * 32 * LS + (ks + 1) * 8);
+#pragma unroll
+          for (int u = 0; u < TN; ++u) bf[nxt][u] = *reinterpret_cast<const float4*>(b + u * 32 * LS + (ks + 1) * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[cur][t].x, bf[cur][u].x, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[cur][t].y, bf[cur][u].y, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[cur][t].z, bf[cur][u].z, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[cur][t].w, bf[cur][u].w, acc[t][u]);
+      }
+      if (kc + 1 < nk) store_tiles(stage ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (m >= g.M) continue;
+      size_t dpix = (size_t)m;
+      if (!g.dst_identity) {
+        const int n = m / OHOW;
+        const int rem = m - n * OHOW;
+        const int oh = rem / g.OW;
+        const int ow = rem - oh * g.OW;
+        dpix = ((size_t)n * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
+      }
+      const float rsc = (g.flags & SRHIP_EPI_ROWSCALE) ? rowscale[dpix] : 1.f;
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int n = n0 + wn * WTN + u * 32 + l31;
+        if (n >= g.K) continue;
+        float v = acc[t][u][r];
+        if (g.flags & SRHIP_EPI_ROWSCALE) v *= rsc;
+        if (g.flags & SRHIP_EPI_BIAS) v += bias[n];
+        if (g.flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
+        if (g.flags & SRHIP_EPI_ACTMASK) v = actmask[dpix * g.ldd + n] > 0.f ? v : v * g.slope;
+        if (g.flags & SRHIP_EPI_RESIDUAL) v += residual[dpix * g.ldr + n];
+        float* o = dst + dpix * g.ldd + n;
+        if (g.accumulate) v += *o;
+        *o = v;
+      }
+    }
+  }
+}
+
+// ================================================================================================ //
+// wgrad: dW[co][(tap,ci)] = sum_p dy[p][co] * xwin[p][(tap,ci)], split over pixel ranges.
+// Both operands are pixel-major, so the LDS images are k-major ([pixel][channel]) and fragments are
+// conflict-free ds_read_b32 of consecutive dwords.  Blocks with tile_n == 0 also emit the column sums
+// of their dy tiles (bias gradient partials).
+// ================================================================================================ //
+struct WgradGeom {
+  int N, H, W, C, ldx;       // x
+  int Ho, Wo, K, ldy;        // dy
+  int KH, KW, stride, pad;
+  int P;                     // N*Ho*Wo pixels
+  int Ktot;                  // KH*KW*C
+  int nsplit, chunks_per_split;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ partial,
+                                                          float* __restrict__ bias_partial,
+                                                          const float* __restrict__ xrow,
+                                                          const float* __restrict__ xchan, WgradGeom g) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int AV = (FBK * BM / 4) / 256, BV = (FBK * BN / 4) / 256;   // float4 per thread per chunk
+  static_assert(AV >= 1 && BV >= 1, "tile too small");
+  constexpr int STAGE = FBK * (LDA + LDB);
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int ntn = (g.Ktot + BN - 1) / BN;
+  const int ntm = (g.K + BM - 1) / BM;
+  int bid = blockIdx.x;
+  const int tile_n = bid % ntn;
+  bid /= ntn;
+  const int tile_m = bid % ntm;
+  const int split = bid / ntm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, g.dy_bytes, 0x00020000);
+
+  const int c_begin = split * g.chunks_per_split;
+  const int nchunks_total = (g.P + FBK - 1) / FBK;
+  const int c_end = min(c_begin + g.chunks_per_split, nchunks_total);
+
+  // A (dy) thread mapping: idx = tid + 256*j -> pixel row arow = idx / (BM/4), column quad ac
+  constexpr int AQ = BM / 4, BQ = BN / 4;
+  const int a_row0 = tid / AQ, a_c = tid - a_row0 * AQ;          // rows a_row0 + j*(256/AQ)
+  const int b_row0 = tid / BQ, b_c = tid - b_row0 * BQ;          // rows b_row0 + j*(256/BQ)
+  const bool a_colok = (m0 + a_c * 4) < g.K;                     // K % 4 == 0 on this path
+  // this thread's B columns (a quad of input channels of ONE filter tap; C % 4 == 0)
+  const int kcol = n0 + b_c * 4;
+  const bool b_colok = kcol < g.Ktot;
+  const int tap = kcol / g.C, ci0 = kcol - tap * g.C;
+  const int kh = tap / g.KW, kw = tap - kh * g.KW;
+
+  // B (x window) per-row pixel coordinates, advanced incrementally by FBK pixels per chunk
+  int bn[BV], bho[BV], bwo[BV];
+#pragma unroll
+  for (int j = 0; j < BV; ++j) {
+    const int p = c_begin * FBK + b_row0 + j * (256 / BQ);
+    const int HoWo = g.Ho * g.Wo;
+    bn[j] = p / HoWo;
+    const int rem = p - bn[j] * HoWo;
+    bho[j] = rem / g.Wo;
+    bwo[j] = rem - bho[j] * g.Wo;
+  }
+
+  float4 ra[AV], rb[BV], rxs[BV];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool xscale = xrow != nullptr || xchan != nullptr;
+  auto load_tiles = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      const int p = kc * FBK + a_row0 + j * (256 / AQ);
+      const unsigned off = (p < g.P && a_colok) ? ((unsigned)p * g.ldy + m0 + a_c * 4) * 4u : F_OOB;
+      ra[j] = bufload4(ry, off);
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int hi = bho[j] * g.stride - g.pad + kh, wi = bwo[j] * g.stride - g.pad + kw;
+      const bool ok = b_colok && bn[j] < g.N && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+      const unsigned off = ok ? ((unsigned)((bn[j] * g.H + hi) * g.W + wi) * g.ldx + ci0) * 4u : F_OOB;
+      rb[j] = bufload4(rx, off);
+      if (xscale) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ok) {
+          if (xchan) sc = *reinterpret_cast<const float4*>(xchan + (size_t)bn[j] * g.C + ci0);
+          if (xrow) {
+            const float r = xrow[(size_t)(bn[j] * g.H + hi) * g.W + wi];
+            sc.x *= r; sc.y *= r; sc.z *= r; sc.w *= r;
+          }
+        }
+        rxs[j] = sc;
+      }
+      bwo[j] += FBK;
+      while (bwo[j] >= g.Wo) {
+        bwo[j] -= g.Wo;
+        if (++bho[j] == g.Ho) {
+          bho[j] = 0;
+          ++bn[j];
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](int stage) {
+    float* a = lds + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < AV; ++j) {
+      *reinterpret_cast<float4*>(a + (a_row0 + j * (256 / AQ)) * LDA + a_c * 4) = ra[j];
+      bsum.x += ra[j].x;
+      bsum.y += ra[j].y;
+      bsum.z += ra[j].z;
+      bsum.w += ra[j].w;
+    }
+    float* b = lds + stage * STAGE + FBK * LDA;
+    if (xscale) {
+#pragma unroll
+      for (int j = 0; j < BV; ++j) {
+        rb[j].x *= rxs[j].x;
+        rb[j].y *= rxs[j].y;
+        rb[j].z *= rxs[j].z;
+        rb[j].w *= rxs[j].w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BV; ++j) *reinterpret_cast<float4*>(b + (b_row0 + j * (256 / BQ)) * LDB + b_c * 4) = rb[j];
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  if (c_begin < c_end) {
+    load_tiles(c_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      const int stage = (kc - c_begin) & 1;
+      if (kc + 1 < c_end) load_tiles(kc + 1);
+      const float* a = lds + stage * STAGE + khalf * LDA + wm * WTM + l31;
+      const float* b = lds + stage * STAGE + FBK * LDA + khalf * LDB + wn * WTN + l31;
+      float av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) av[0][t] = a[t * 32];
+#pragma unroll
+      for (int u = 0; u < TN; ++u) bv[0][u] = b[u * 32];
+#pragma unroll
+      for (int kk = 0; kk < FBK / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < FBK / 2) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) av[nxt][t] = a[(kk + 1) * 2 * LDA + t * 32];
+#pragma unroll
+          for (int u = 0; u < TN; ++u) bv[nxt][u] = b[(kk + 1) * 2 * LDB + u * 32];
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(av[cur][t], bv[cur][u], acc[t][u]);
+      }
+      if (kc + 1 < c_end) store_tiles(stage ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = partial + (size_t)split * g.K * g.Ktot;
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = n0 + wn * WTN + u * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m < g.K && n < g.Ktot) out[(size_t)m * g.Ktot + n] = acc[t][u][r];
+      }
+  }
+
+  // bias-gradient partial: column sums of every dy tile this block staged (only the tile_n == 0 blocks)
+  if (bias_partial != nullptr && tile_n == 0) {
+    __syncthreads();
+    float* red = lds;                                  // [256/AQ][BM]
+    *reinterpret_cast<float4*>(red + a_row0 * BM + a_c * 4) = bsum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.K) {
+      float s = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 256 / AQ; ++rr) s += red[rr * BM + tid];
+      bias_partial[(size_t)split * g.K + m0 + tid] = s;
+    }
+  }
+}
+
+// partial[s][co][(tap,ci)] --sum over s--> dw[co][ci][kh][kw];  bias_partial[s][co] --> db[co]
+__global__ void fast_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
+                                         float* __restrict__ dw, float* __restrict__ db, int nsplit, int cout,
+                                         int cin, int khkw, int ktot) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = cout * ktot;
+  if (idx < total) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= nsplit; i += 4) {
+      s0 += partial[(size_t)(i + 0) * total + idx];
+      s1 += partial[(size_t)(i + 1) * total + idx];
+      s2 += partial[(size_t)(i + 2) * total + idx];
+      s3 += partial[(size_t)(i + 3) * total + idx];
+    }
+    for (; i < nsplit; ++i) s0 += partial[(size_t)i * total + idx];
+    const int co = idx / ktot, kcol = idx - co * ktot;
+    const int tap = kcol / cin, ci = kcol - tap * cin;
+    dw[((size_t)co * cin + ci) * khkw + tap] = (s0 + s1) + (s2 + s3);
+  } else if (db != nullptr && idx < total + cout) {
+    const int co = idx - total;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += bias_partial[(size_t)i * cout + co];
+    db[co] = s;
+  }
+}
+
+// OIHW -> n-major packed GEMM operand.
+// mode 0 (fprop): P[co][(kh*KW+kw)*Cin + ci]  = w[co][ci][kh][kw]
+// mode 1 (dgrad): P[ci][(kh*KW+kw)*Cout + co] = w[co][ci][kh][kw]
+__global__ void fast_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout, int cin, int kh,
+                                 int kw, int mode) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = cout * cin * kh * kw;
+  if (idx >= total) return;
+  const int khkw = kh * kw;
+  if (mode == 0) {
+    const int co = idx / (khkw * cin);
+    const int rem = idx - co * khkw * cin;
+    const int tap = rem / cin, ci = rem - tap * cin;
+    packed[idx] = w[((size_t)co * cin + ci) * khkw + tap];
+  } else {
+    const int ci = idx / (khkw * cout);
+    const int rem = idx - ci * khkw * cout;
+    const int tap = rem / cout, co = rem - tap * cout;
+    packed[idx] = w[((size_t)co * cin + ci) * khkw + tap];
+  }
+}
+
+// ================================================================================================ //
+// host side
+// ================================================================================================ //
+static bool shape_ok(int csrc, int kh, int kw) { return csrc % 16 == 0 && kh * kw <= 32 && kh == kw; }
+bool fast_fwd_ok(int cin, int cout, int kh, int kw) { return shape_ok(cin, kh, kw); }
+bool fast_dgrad_ok(int cin, int cout, int kh, int kw) { return shape_ok(cout, kh, kw); }
+bool fast_wgrad_ok(int cin, int cout, int kh, int kw) { return cin % 16 == 0 && cout % 4 == 0 && kh == kw; }
+
+int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, hipStream_t st) {
+  const long total = (long)cout * cin * kh * kw;
+  hipLaunchKernelGGL(fast_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, packed, cout, cin, kh, kw, mode);
+  return check_launch("fast_pack_weight");
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_fast(const float* src, const float* wt, const float* bias, const float* residual,
+                       const float* rowscale, const float* chanscale, const float* actmask, float* dst,
+                       const FastGeom& g, hipStream_t st) {
+  const int nbm = cdiv(g.M, BM), nbn = cdiv(g.K, BN);
+  hipLaunchKernelGGL((fast_conv_kernel<BM, BN, WM, WN, BK>), dim3(nbm * nbn), dim3(WM * WN * 64), 0, st, src, wt, bias,
+                     residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
+  return check_launch("fast_conv");
+}
+
+// experiment knob (srhip_debug_set(0, cfg)): 0 = heuristic below
+int g_fast_cfg = 0;
+
+static int run_fast(const float* src, const float* wt, const float* bias, const float* residual,
+                    const float* rowscale, const float* chanscale, const float* actmask, float* dst, const FastGeom& g,
+                    hipStream_t st) {
+  if (g.M <= 0) return SRHIP_OK;
+#define SRHIP_LF(BM_, BN_, WM_, WN_, BK_) \
+  return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
+  if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
+  const bool k32 = g.C % 32 == 0;
+  if (g_fast_cfg == 1 && g.K >= 128 && k32) SRHIP_LF(128, 128, 2, 2, 32);
+  if (g_fast_cfg == 2 && g.K >= 128) SRHIP_LF(64, 128, 1, 4, 16);
+  if (g_fast_cfg == 3 && g.K >= 128 && k32) SRHIP_LF(64, 128, 1, 4, 32);
+  if (g_fast_cfg == 4 && g.K >= 128) SRHIP_LF(256, 128, 4, 2, 16);
+  if (g_fast_cfg == 5 && g.K >= 128) SRHIP_LF(128, 128, 2, 2, 16);
+  if (g_fast_cfg == 6 && k32) SRHIP_LF(128, 64, 2, 2, 32);
+  if (g_fast_cfg == 7) SRHIP_LF(64, 64, 2, 2, 16);
+  if (g_fast_cfg == 8 && k32) SRHIP_LF(128, 64, 4, 1, 32);
+  const long b128 = (long)cdiv(g.M, 128) * cdiv(g.K, 128);
+  if (g.K >= 128 && b128 >= 512) SRHIP_LF(128, 128, 2, 2, 16);
+  const long b64 = (long)cdiv(g.M, 128) * cdiv(g.K, 64);
+  if (b64 >= 512) SRHIP_LF(128, 64, 2, 2, 16);
+  SRHIP_LF(64, 64, 2, 2, 16);
+#undef SRHIP_LF
+}
+
+static bool bytes_ok(long pixels, int ld, int c, unsigned* out) {
+  const long b = pixels > 0 ? ((pixels - 1) * (long)ld + c) * 4L : 0;
+  if (b >= (1L << 31)) return false;
+  *out = (unsigned)b;
+  return true;
+}
+
+int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+                    const float* rowscale, const float* chanscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,
+                    int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, hipStream_t st) {
+  SRHIP_REQUIRE(ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)packed) & 15) == 0, "conv2d_fwd: x/packed must be 16-byte aligned with ldx % 4 == 0");
+  FastGeom g;
+  g.N = n; g.Hs = h; g.Ws = w; g.C = cin; g.lds = ldx;
+  g.OH = (h + 2 * pad - kh) / stride + 1;
+  g.OW = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(g.OH > 0 && g.OW > 0, "conv2d_fwd: empty output");
+  const long M = (long)n * g.OH * g.OW;
+  SRHIP_REQUIRE(M < (1L << 31), "conv2d_fwd: pixel count overflows int32");
+  g.M = (int)M; g.ss = stride;
+  g.TH = kh; g.TW = kw; g.dh0 = -pad; g.dhs = 1; g.dw0 = -pad; g.dws = 1;
+  g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1; g.KW = kw;
+  g.Hd = g.OH; g.Wd = g.OW; g.dsd = 1; g.ph = 0; g.pw = 0; g.ldd = ldy; g.K = cout;
+  g.ldw = kh * kw * cin; g.ldr = ldr; g.slope = slope; g.flags = flags; g.accumulate = 0; g.dst_identity = 1;
+  SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.src_bytes), "conv2d_fwd: source tensor >= 2 GiB");
+  g.w_bytes = (unsigned)((long)cout * g.ldw * 4);
+  return run_fast(x, packed, bias, residual, rowscale, chanscale, nullptr, y, g, st);
+}
+
+int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,
+                      float slope, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldy,
+                      int ldx, int ldr, int accumulate, hipStream_t st) {
+  SRHIP_REQUIRE(ldy % 4 == 0 && (((uintptr_t)dy | (uintptr_t)packed) & 15) == 0, "conv2d_dgrad: dy/packed must be 16-byte aligned with ldy % 4 == 0");
+  const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(ho > 0 && wo > 0, "conv2d_dgrad: empty dy");
+  FastGeom g;
+  g.N = n; g.Hs = ho; g.Ws = wo; g.C = cout; g.lds = ldy;
+  g.KW = kw; g.Hd = h; g.Wd = w; g.dsd = stride; g.ldd = ldx; g.K = cin;
+  g.ldw = kh * kw * cout; g.ldr = ldr; g.slope = slope; g.accumulate = accumulate ? 1 : 0;
+  g.flags = (residual ? SRHIP_EPI_RESIDUAL : 0) | (actmask ? SRHIP_EPI_ACTMASK : 0);
+  g.ss = 1; g.dhs = -1; g.dws = -1; g.khs = stride; g.kws = stride;
+  g.dst_identity = stride == 1 ? 1 : 0;
+  SRHIP_REQUIRE(bytes_ok((long)n * ho * wo, ldy, cout, &g.src_bytes), "conv2d_dgrad: dy tensor >= 2 GiB");
+  g.w_bytes = (unsigned)((long)cin * g.ldw * 4);
+  // dx[hh] gathers dy[(hh + pad - kh)/stride] for kh == (hh + pad) mod stride: one dense GEMM per phase
+  for (int ph = 0; ph < stride; ++ph) {
+    for (int pw = 0; pw < stride; ++pw) {
+      g.ph = ph; g.pw = pw;
+      g.OH = (h - ph + stride - 1) / stride;
+      g.OW = (w - pw + stride - 1) / stride;
+      if (g.OH <= 0 || g.OW <= 0) continue;
+      g.kh0 = (ph + pad) % stride; g.kw0 = (pw + pad) % stride;
+      g.TH = g.kh0 < kh ? (kh - g.kh0 + stride - 1) / stride : 0;
+      g.TW = g.kw0 < kw ? (kw - g.kw0 + stride - 1) / stride : 0;
+      if (g.TH == 0 || g.TW == 0) { g.TH = 0; g.TW = 0; }
+      g.dh0 = (ph + pad - g.kh0) / stride; g.dw0 = (pw + pad - g.kw0) / stride;
+      const long M = (long)n * g.OH * g.OW;
+      SRHIP_REQUIRE(M < (1L << 31), "conv2d_dgrad: pixel count overflows int32");
+      g.M = (int)M;
+      int rc = run_fast(dy, packed, nullptr, residual, nullptr, nullptr, actmask, dx, g, st);
+      if (rc) return rc;
+    }
+  }
+  return SRHIP_OK;
+}
+
+// ---- wgrad ------------------------------------------------------------------------------------- //
+struct FastWgradPlan {
+  int bm, bn, nsplit, chunks_per_split;
+};
+int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128
+static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
+  FastWgradPlan p;
+  p.bm = cout > 64 ? 128 : 64;
+  p.bn = ktot >= 128 ? 128 : 64;
+  if (g_wgrad_cfg == 1) p.bn = 64;
+  if (g_wgrad_cfg == 2) p.bn = 128;
+  const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
+  const int nchunks = cdiv(P, FBK);
+  long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
+  const long maxsplit = (nchunks + 15) / 16;          // at least 16 chunks (256 pixels) per split
+  if (ns > maxsplit) ns = maxsplit;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  p.chunks_per_split = (int)((nchunks + ns - 1) / ns);
+  p.nsplit = cdiv(nchunks, p.chunks_per_split);
+  return p;
+}
+
+size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  const long P = (long)n * ho * wo;
+  if (P <= 0) return 0;
+  FastWgradPlan p = plan_fast_wgrad(P, cout, kh * kw * cin);
+  return (size_t)p.nsplit * ((size_t)cout * kh * kw * cin + cout) * sizeof(float);
+}
+
+int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrow, const float* xchan,
+                      void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
+                      hipStream_t st) {
+  SRHIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
+                "conv2d_wgrad: x/dy must be 16-byte aligned with row strides % 4 == 0");
+  WgradGeom g;
+  g.N = n; g.H = h; g.W = w; g.C = cin; g.ldx = ldx;
+  g.Ho = (h + 2 * pad - kh) / stride + 1;
+  g.Wo = (w + 2 * pad - kw) / stride + 1;
+  SRHIP_REQUIRE(g.Ho > 0 && g.Wo > 0, "conv2d_wgrad: empty output");
+  g.K = cout; g.ldy = ldy; g.KH = kh; g.KW = kw; g.stride = stride; g.pad = pad;
+  const long P = (long)n * g.Ho * g.Wo;
+  SRHIP_REQUIRE(P < (1L << 31) - 64, "conv2d_wgrad: pixel count overflows int32");
+  g.P = (int)P; g.Ktot = kh * kw * cin;
+  SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.x_bytes) && bytes_ok(P, ldy, cout, &g.dy_bytes),
+                "conv2d_wgrad: tensor >= 2 GiB");
+  FastWgradPlan p = plan_fast_wgrad(P, cout, g.Ktot);
+  g.nsplit = p.nsplit; g.chunks_per_split = p.chunks_per_split;
+  const size_t need = (size_t)p.nsplit * ((size_t)cout * g.Ktot + cout) * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_error("conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return SRHIP_ERR_WORKSPACE;
+  }
+  float* partial = static_cast<float*>(workspace);
+  float* bias_partial = partial + (size_t)p.nsplit * cout * g.Ktot;
+  const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
+#define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                          \
+  hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
+                     db ? bias_partial : nullptr, xrow, xchan, g)
+  if (p.bm == 128 && p.bn == 128)
+    SRHIP_LW(128, 128, 2, 2);
+  else if (p.bm == 128)
+    SRHIP_LW(128, 64, 2, 2);
+  else if (p.bn == 128)
+    SRHIP_LW(64, 128, 1, 4);
+  else
+    SRHIP_LW(64, 64, 2, 2);
+#undef SRHIP_LW
+  int rc = check_launch("fast_wgrad");
+  if (rc) return rc;
+  const long total = (long)cout * g.Ktot + (db ? cout : 0);
+  hipLaunchKernelGGL(fast_wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, bias_partial, dw,
+                     db, p.nsplit, cout, cin, kh * kw, g.Ktot);
+  return check_launch("fast_wgrad_reduce");
+}
+
+}  // namespace srhip

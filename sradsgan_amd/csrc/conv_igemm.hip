@@ -507,24 +507,22 @@ static WgradPlan plan_wgrad(int M, int cout, int ktot) {
 
 }  // namespace srhip
 
-using namespace srhip;
+namespace srhip {
 
-extern "C" {
+int legacy_packed_ld(int cdst) { return ((cdst + 31) / 32) * 32; }
 
-int srhip_packed_ld(int cdst) { return ((cdst + 31) / 32) * 32; }
-
-int srhip_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, void* stream) {
+int legacy_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, void* stream) {
   SRHIP_REQUIRE(w && packed && cout > 0 && cin > 0 && kh > 0 && kw > 0 && (mode == 0 || mode == 1),
                 "pack_weight: bad argument");
   int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
-  int ld = srhip_packed_ld(cdst);
+  int ld = legacy_packed_ld(cdst);
   long total = (long)kh * kw * csrc * ld;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, packed, cout,
                      cin, kh, kw, mode, ld);
   return check_launch("pack_weight");
 }
 
-int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
+int legacy_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                      const float* rowscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,
                      int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, void* stream) {
   SRHIP_REQUIRE(x && packed && y, "conv2d_fwd: null tensor");
@@ -540,7 +538,7 @@ int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, con
   g.Wo = (w + 2 * pad - kw) / stride + 1;
   SRHIP_REQUIRE(g.Ho > 0 && g.Wo > 0, "conv2d_fwd: empty output");
   g.K = cout; g.KH = kh; g.KW = kw; g.so = stride; g.pad = pad; g.dv = 1;
-  g.ldx = ldx; g.ldy = ldy; g.ldr = ldr; g.ldw = srhip_packed_ld(cout);
+  g.ldx = ldx; g.ldy = ldy; g.ldr = ldr; g.ldw = legacy_packed_ld(cout);
   g.Ktot = kh * kw * cin;
   long M = (long)n * g.Ho * g.Wo;
   SRHIP_REQUIRE(M < (1L << 31) && (long)n * h * w < (1L << 31), "conv2d_fwd: pixel count overflows int32");
@@ -548,7 +546,7 @@ int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, con
   return run_fprop(x, packed, bias, residual, rowscale, y, g, as_stream(stream));
 }
 
-int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, int h, int w, int cin, int cout,
+int legacy_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, int h, int w, int cin, int cout,
                        int kh, int kw, int stride, int pad, int ldy, int ldx, int accumulate, void* stream) {
   SRHIP_REQUIRE(dy && packed && dx, "conv2d_dgrad: null tensor");
   SRHIP_REQUIRE(n >= 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
@@ -564,7 +562,7 @@ int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, i
   g.C = cout; g.Ho = h; g.Wo = w; g.K = cin; g.KH = kh; g.KW = kw;
   g.so = 1; g.pad = kh - 1 - pad; g.dv = stride;
   SRHIP_REQUIRE(kh == kw, "conv2d_dgrad: square kernels only");
-  g.ldx = ldy; g.ldy = ldx; g.ldr = 0; g.ldw = srhip_packed_ld(cin);
+  g.ldx = ldy; g.ldy = ldx; g.ldr = 0; g.ldw = legacy_packed_ld(cin);
   g.Ktot = kh * kw * cout;
   long M = (long)n * h * w;
   SRHIP_REQUIRE(M < (1L << 31), "conv2d_dgrad: pixel count overflows int32");
@@ -572,7 +570,7 @@ int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, i
   return run_fprop(dy, packed, nullptr, nullptr, nullptr, dx, g, as_stream(stream));
 }
 
-size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+size_t legacy_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
   int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
   long M = (long)n * ho * wo;
   if (M <= 0) return 0;
@@ -580,7 +578,7 @@ size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int 
   return (size_t)p.nsplit * cout * kh * kw * cin * sizeof(float);
 }
 
-int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
+int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
                        int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
                        void* stream) {
   SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
@@ -621,4 +619,4 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspa
   return check_launch("wgrad_reduce");
 }
 
-}  // extern "C"
+}  // namespace srhip

@@ -1,6 +1,6 @@
 // HBM-bound pieces of the SRADSGAN step: activation backward, pixel shuffle, column sums.
 // All are one pass over the tensor with 16-byte accesses; roofline = HBM bandwidth.
-#include "common.h"
+#include "conv_internal.h"
 
 #include <string.h>
 
@@ -91,37 +91,66 @@ __global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dout, const f
   d[3 * r * r] = g.w;
 }
 
-// column sums of a [rows][ld] matrix, first C columns; stage 1: each block reduces ROWS_PER_BLOCK rows
-constexpr int CS_ROWS = 512;
-__global__ void colsum_stage1(const float* __restrict__ dy, float* __restrict__ partial, long rows, int c, int ld) {
-  __shared__ float red[256];
+// column sums of a [rows][ld] matrix, first C columns (bias gradient on the generic conv path).
+// stage 1: <= 1024 blocks, each reduces a contiguous slab of rows with 16-byte loads (T = float4)
+// or scalar loads (T = float); stage 2: 4 row-lanes per column over the block partials.
+template <typename T>
+__global__ void colsum_stage1(const float* __restrict__ dy, float* __restrict__ partial, long rows, int c, int ld,
+                              long rows_per_block) {
+  constexpr int V = sizeof(T) / 4;
+  __shared__ T red[256];
   const int tid = threadIdx.x;
-  const int cols_per_pass = c < 256 ? c : 256;     // threads along columns
-  const int rlanes = 256 / cols_per_pass;          // threads along rows (>=1)
-  const long r0 = (long)blockIdx.x * CS_ROWS;
-  const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-  for (int cbase = 0; cbase < c; cbase += cols_per_pass) {
-    int col = cbase + tid % cols_per_pass;
-    int rl = tid / cols_per_pass;
-    float s = 0.f;
-    if (col < c && rl < rlanes)
-      for (long r = r0 + rl; r < r1; r += rlanes) s += dy[(size_t)r * ld + col];
-    red[tid] = s;
-    __syncthreads();
-    if (rl == 0 && col < c) {
-      float t = 0.f;
-      for (int k = 0; k < rlanes; ++k) t += red[k * cols_per_pass + tid];
-      partial[(size_t)blockIdx.x * c + col] = t;
+  const int q = c / V;                       // column groups (q <= 256)
+  const int nrl = 256 / q;                   // row lanes
+  const int cq = tid % q, rl = tid / q;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  T s;
+  for (int e = 0; e < V; ++e) reinterpret_cast<float*>(&s)[e] = 0.f;
+  if (rl < nrl)
+    for (long r = r0 + rl; r < r1; r += nrl) {
+      T v = *reinterpret_cast<const T*>(dy + (size_t)r * ld + cq * V);
+      for (int e = 0; e < V; ++e) reinterpret_cast<float*>(&s)[e] += reinterpret_cast<float*>(&v)[e];
     }
-    __syncthreads();
+  red[tid] = s;
+  __syncthreads();
+  if (tid < q) {
+    T t = red[tid];
+    for (int k = 1; k < nrl; ++k) {
+      T v = red[k * q + tid];
+      for (int e = 0; e < V; ++e) reinterpret_cast<float*>(&t)[e] += reinterpret_cast<float*>(&v)[e];
+    }
+    *reinterpret_cast<T*>(partial + (size_t)blockIdx.x * c + tid * V) = t;
   }
 }
 __global__ void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk, int c) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= c) return;
+  __shared__ float red[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * c + col];
-  out[col] = s;
+  if (col < c)
+    for (int b = sub; b < nblk; b += 4) s += partial[(size_t)b * c + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && col < c)
+    out[col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+static long colsum_nblk(long rows) {
+  long nblk = (rows + 63) / 64;
+  return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);
+}
+size_t colsum_workspace_bytes(long rows, int c) { return (size_t)colsum_nblk(rows) * c * sizeof(float); }
+
+int colsum_launch(const float* dy, float* db, void* workspace, long rows, int c, int ld, hipStream_t st) {
+  const long nblk = colsum_nblk(rows);
+  const long rpb = (rows + nblk - 1) / nblk;
+  const bool vec = (c % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)dy % 16 == 0) && c <= 1024;
+  if (vec)
+    hipLaunchKernelGGL(colsum_stage1<float4>, dim3((int)nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld, rpb);
+  else
+    hipLaunchKernelGGL(colsum_stage1<float>, dim3((int)nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld, rpb);
+  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, (const float*)workspace, db, (int)nblk, c);
+  return check_launch("colsum");
 }
 
 }  // namespace srhip
@@ -175,24 +204,18 @@ int srhip_pixel_shuffle_bwd(const float* dout, const float* out, float* din, int
   return check_launch("pixel_shuffle_bwd");
 }
 
-size_t srhip_colsum_workspace(long rows, int c) {
-  long nblk = (rows + CS_ROWS - 1) / CS_ROWS;
-  return (size_t)(nblk > 0 ? nblk : 1) * c * sizeof(float);
-}
+size_t srhip_colsum_workspace(long rows, int c) { return colsum_workspace_bytes(rows, c); }
 
 int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_bytes, long rows, int c, int ld,
                  void* stream) {
   SRHIP_REQUIRE(dy && db && rows > 0 && c > 0 && ld >= c, "colsum: bad argument");
-  size_t need = srhip_colsum_workspace(rows, c);
+  SRHIP_REQUIRE(c % 4 == 0 ? c <= 1024 : c <= 256, "colsum: too many columns");
+  size_t need = colsum_workspace_bytes(rows, c);
   if (!workspace || workspace_bytes < need) {
     set_error("colsum: workspace %zu bytes < required %zu", workspace_bytes, need);
     return SRHIP_ERR_WORKSPACE;
   }
-  int nblk = (int)((rows + CS_ROWS - 1) / CS_ROWS);
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld);
-  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(c, 256)), dim3(256), 0, st, (const float*)workspace, db, nblk, c);
-  return check_launch("colsum");
+  return colsum_launch(dy, db, workspace, rows, c, ld, as_stream(stream));
 }
 
 }  // extern "C"

@@ -93,6 +93,10 @@ class _AttentionTail:
     def _tail(self, out, skip):
         """attention tail followed by `out += skip`; the add is fused into the closing 1x1 conv."""
         m = self.la_mode
+        if (m == 'CA-SA' and self.addconv and self.ca.pool_mode == 'Avg|Max' and self.sa.pool_mode == 'Avg|Max'
+                and ops.attention_tail_supported(out, self.ca.fc1.weight, self.sa.conv1.weight, self.conv.weight)):
+            return ops.attention_tail(out, skip, self.ca.fc1.weight, self.ca.fc2.weight, self.sa.conv1.weight,
+                                      self.conv.weight, self.conv.bias)
         if m in ('CA-SA', 'SA-CA'):
             first, second = (self.ca, self.sa) if m == 'CA-SA' else (self.sa, self.ca)
             out = second(first(out))
@@ -121,7 +125,17 @@ class RAB(nn.Module, _AttentionTail):
         self.conv2 = HipConv2d(4 * planes, planes, kernel_size, stride, padding, bias=bias, dilation=dilation)
         self._build_tail(la_mode, pool_mode, planes, addconv)
 
+    def _fusable(self, x):
+        return (self.la_mode == 'CA-SA' and self.addconv and self.ca.pool_mode == 'Avg|Max'
+                and self.sa.pool_mode == 'Avg|Max' and self.inplanes == 64 and self.planes == 64
+                and self.conv1.kernel_size == (3, 3) and self.conv1.stride == (1, 1) and self.conv1.padding == (1, 1)
+                and ops.attention_tail_supported(x, self.ca.fc1.weight, self.sa.conv1.weight, self.conv.weight))
+
     def forward(self, x):
+        if self._fusable(x):
+            return ops.rab_block(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                 self.ca.fc1.weight, self.ca.fc2.weight, self.sa.conv1.weight, self.conv.weight,
+                                 self.conv.bias)
         out = self.conv2(self.conv1(x, act_slope=0.2))
         return self._tail(out, x)
 

@@ -17,7 +17,7 @@ from torch.autograd import Function
 
 from . import _hip
 
-EPI_BIAS, EPI_LRELU, EPI_RESIDUAL, EPI_ROWSCALE = 1, 2, 4, 8
+EPI_BIAS, EPI_LRELU, EPI_RESIDUAL, EPI_ROWSCALE, EPI_CHANSCALE = 1, 2, 4, 8, 16
 CL = torch.channels_last
 
 class _State:
@@ -95,9 +95,7 @@ def packed_weight(w, mode):
             return ent[mode][1]
     wd = w.detach().contiguous()
     lib = _hip.lib()
-    csrc, cdst = (cin, cout) if mode == 0 else (cout, cin)
-    ld = lib.srhip_packed_ld(cdst)
-    packed = torch.empty((kh * kw * csrc, ld), device=w.device, dtype=torch.float32)
+    packed = torch.empty(lib.srhip_packed_elems(cout, cin, kh, kw, mode), device=w.device, dtype=torch.float32)
     _hip.check(lib.srhip_pack_weight(_p(wd), _p(packed), cout, cin, kh, kw, mode, _stream()), 'pack_weight')
     if cacheable:
         if getattr(w, '_srhip_packed', None) is None:
@@ -110,7 +108,7 @@ def _out_hw(h, w, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None):
+def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None):
     _require_gpu(x, 'conv2d_fwd')
     x = nhwc(x)
     n, cin, h, wd = x.shape
@@ -131,26 +129,38 @@ def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=
     if rowscale is not None:
         rowscale = rowscale.contiguous()
         flags |= EPI_ROWSCALE
+    if chanscale is not None:
+        chanscale = chanscale.contiguous()
+        flags |= EPI_CHANSCALE
     lib = _hip.lib()
-    _hip.check(lib.srhip_conv2d_fwd(_p(x), _p(packed_weight(w, 0)), _p(bias), _p(residual), _p(rowscale), _p(y),
+    _hip.check(lib.srhip_conv2d_fwd(_p(x), _p(packed_weight(w, 0)), _p(bias), _p(residual), _p(rowscale),
+                                    _p(chanscale), _p(y),
                                     n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout, cout,
                                     float(slope or 0.0), flags, _stream()), 'conv2d_fwd')
     return y
 
 
-def conv2d_dgrad_raw(dy, w, x_shape, stride, pad):
+def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, slope=0.0):
+    """dx = conv_transpose(dy, w) [* lrelu'(actmask)] [+ residual]: the optional tail fuses the backward
+    of the LeakyReLU that produced this conv's input and the skip-path gradient add."""
     _require_gpu(dy, 'conv2d_dgrad')
     dy = nhwc(dy)
     n, cin, h, wd = x_shape
     cout, _, kh, kw = w.shape
     dx = empty_nhwc(n, cin, h, wd, dy)
+    if residual is not None:
+        residual = nhwc(residual)
+    if actmask is not None:
+        actmask = nhwc(actmask)
     lib = _hip.lib()
-    _hip.check(lib.srhip_conv2d_dgrad(_p(dy), _p(packed_weight(w, 1)), _p(dx), n, h, wd, cin, cout, kh, kw, stride,
-                                      pad, cout, cin, 0, _stream()), 'conv2d_dgrad')
+    _hip.check(lib.srhip_conv2d_dgrad(_p(dy), _p(packed_weight(w, 1)), _p(dx), _p(residual), _p(actmask), float(slope),
+                                      n, h, wd, cin, cout, kh, kw, stride, pad, cout, cin, cin, 0, _stream()),
+               'conv2d_dgrad')
     return dx
 
 
-def conv2d_wgrad_raw(x, dy, w_shape, stride, pad):
+def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=None, xchanscale=None):
+    """(dw [OIHW], db [Cout] or None): the bias gradient comes out of the same kernel pass."""
     _require_gpu(x, 'conv2d_wgrad')
     x, dy = nhwc(x), nhwc(dy)
     n, cin, h, wd = x.shape
@@ -159,9 +169,10 @@ def conv2d_wgrad_raw(x, dy, w_shape, stride, pad):
     nbytes = lib.srhip_conv2d_wgrad_workspace(n, h, wd, cin, cout, kh, kw, stride, pad)
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=x.device, dtype=torch.float32)
     dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
-    _hip.check(lib.srhip_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(ws), ws.numel() * 4, n, h, wd, cin, cout, kh, kw,
-                                      stride, pad, cin, cout, _stream()), 'conv2d_wgrad')
-    return dw
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
+    _hip.check(lib.srhip_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(xrowscale), _p(xchanscale), _p(ws), ws.numel() * 4, n, h, wd, cin, cout, kh,
+                                      kw, stride, pad, cin, cout, _stream()), 'conv2d_wgrad')
+    return dw, db
 
 
 def colsum_raw(dy):
@@ -236,8 +247,12 @@ class _ConvFwd(Function):
         g = dy if ctx.slope is None else _LReluBwd.apply(dy, y, ctx.slope)
         skip = _skip_param_grads()
         dx = _ConvDgrad.apply(g, w, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
-        dw = _ConvWgrad.apply(x, g, tuple(w.shape), ctx.stride, ctx.pad) if (ctx.needs_input_grad[1] and not skip) else None
-        db = _ColSum.apply(g) if (ctx.has_bias and ctx.needs_input_grad[2] and not skip) else None
+        dw = db = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not skip
+        if ctx.needs_input_grad[1] and not skip:
+            dw, db = _ConvWgrad.apply(x, g, tuple(w.shape), ctx.stride, ctx.pad, want_b)
+        elif want_b:
+            db = _ColSum.apply(g)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None
 
@@ -256,26 +271,38 @@ class _ConvDgrad(Function):
         dy, w = ctx.saved_tensors
         skip = _skip_param_grads()
         d_dy = _ConvFwd.apply(ddx, w, None, None, ctx.stride, ctx.pad, None) if ctx.needs_input_grad[0] else None
-        d_w = _ConvWgrad.apply(ddx, dy, tuple(w.shape), ctx.stride, ctx.pad) if (ctx.needs_input_grad[1] and not skip) else None
+        d_w = None
+        if ctx.needs_input_grad[1] and not skip:
+            d_w, _ = _ConvWgrad.apply(ddx, dy, tuple(w.shape), ctx.stride, ctx.pad, False)
         return d_dy, d_w, None, None, None
 
 
 class _ConvWgrad(Function):
-    """dw = wgrad(x, dy): bilinear in (x, dy)."""
+    """(dw, db) = wgrad(x, dy): dw bilinear in (x, dy), db = sum of dy over pixels."""
 
     @staticmethod
-    def forward(ctx, x, dy, w_shape, stride, pad):
+    def forward(ctx, x, dy, w_shape, stride, pad, with_bias):
         ctx.stride, ctx.pad, ctx.w_shape = stride, pad, w_shape
         ctx.save_for_backward(x, dy)
-        return conv2d_wgrad_raw(x, dy, w_shape, stride, pad)
+        dw, db = conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias)
+        if db is None:
+            ctx.mark_non_differentiable()
+        return dw, db
 
     @staticmethod
-    def backward(ctx, ddw):
+    def backward(ctx, ddw, ddb):
         x, dy = ctx.saved_tensors
-        ddw = ddw.contiguous()
-        d_x = _ConvDgrad.apply(dy, ddw, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
-        d_dy = _ConvFwd.apply(x, ddw, None, None, ctx.stride, ctx.pad, None) if ctx.needs_input_grad[1] else None
-        return d_x, d_dy, None, None, None
+        d_x = d_dy = None
+        if ddw is not None:
+            ddw = ddw.contiguous()
+            if ctx.needs_input_grad[0]:
+                d_x = _ConvDgrad.apply(dy, ddw, tuple(x.shape), ctx.stride, ctx.pad)
+            if ctx.needs_input_grad[1]:
+                d_dy = _ConvFwd.apply(x, ddw, None, None, ctx.stride, ctx.pad, None)
+        if ddb is not None and ctx.needs_input_grad[1]:
+            e = ddb.view(1, -1, 1, 1).expand(dy.shape)
+            d_dy = e if d_dy is None else d_dy + e
+        return d_x, d_dy, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=None, residual=None):
@@ -320,6 +347,132 @@ def pixel_shuffle_act(x, r, slope=None):
 
 
 # --------------------------------------------------------------------------------------------- #
+# fused local-attention tail of RAB / ResGroup: CLAM -> SLAM -> conv1x1 (+bias) -> += skip
+# (sradsgan.py:254-274, 303-323).  y = s*u and z = m*y are never written to HBM.
+# --------------------------------------------------------------------------------------------- #
+
+
+def _clam_logits(avg, mx, fc1_w, fc2_w):
+    """[B,C] pooled vectors -> sigmoid(MLP(avg) + MLP(max)) (sradsgan.py:110-112,124-126)."""
+    hid, c = fc1_w.shape[0], fc1_w.shape[1]
+    w1, w2 = fc1_w.reshape(hid, c), fc2_w.reshape(c, hid)
+    return torch.sigmoid(torch.relu(avg @ w1.t()) @ w2.t() + torch.relu(mx @ w1.t()) @ w2.t())
+
+
+def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
+    """returns (out, tensors to save for _tail_backward)."""
+    n, c, h, w = u.shape
+    lib = _hip.lib()
+    dev = u.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    avg, mx, s = torch.empty(n, c, **f32), torch.empty(n, c, **f32), torch.empty(n, c, **f32)
+    arg = torch.empty(n, c, device=dev, dtype=torch.int32)
+    pooled, m = torch.empty(n * h * w, 2, **f32), torch.empty(n * h * w, **f32)
+    argc = torch.empty(n * h * w, device=dev, dtype=torch.int32)
+    ws = torch.empty(lib.srhip_attn_tail_workspace(n) // 4, **f32)
+    fc1c, fc2c, w7c = fc1_w.detach().contiguous(), fc2_w.detach().contiguous(), w7.detach().contiguous()
+    _hip.check(lib.srhip_attn_tail_fwd(_p(u), _p(fc1c), _p(fc2c), _p(w7c), _p(avg), _p(mx), _p(arg), _p(s),
+                                       _p(pooled), _p(argc), _p(m), _p(ws), ws.numel() * 4, n, h, w, c,
+                                       fc1_w.shape[0], _stream()), 'attn_tail_fwd')
+    out = conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s)
+    return out, (avg, mx, arg, s, pooled, argc, m)
+
+
+def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, has_bias, skip_params=False):
+    """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc)."""
+    avg, mx, arg, s, pooled, argc, m = saved
+    n, c, h, w = u.shape
+    lib = _hip.lib()
+    f32 = dict(device=u.device, dtype=torch.float32)
+    dz = conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)                              # gradient at z = m*s*u
+    dwc = dbc = None
+    if not skip_params:
+        dwc, dbc = conv2d_wgrad_raw(u, g, tuple(wc.shape), 1, 0, has_bias, m, s)    # x operand = z, rebuilt on the fly
+    du = torch.empty_like(u, memory_format=CL)
+    ds, dw7 = torch.empty(n, c, **f32), torch.empty(w7.shape, **f32)
+    ws = torch.empty(lib.srhip_attn_tail_bwd_workspace(n, h, w) // 4, **f32)
+    _hip.check(lib.srhip_attn_tail_bwd_spatial(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc),
+                                               _p(w7.detach().contiguous()), _p(du), _p(ds), _p(dw7), _p(ws),
+                                               ws.numel() * 4, n, h, w, c, _stream()), 'attn_tail_bwd_spatial')
+    # channel half: ds -> sigmoid -> shared MLP -> (davg, dmax, dfc1, dfc2); [B,64] tensors, torch autograd
+    with torch.enable_grad():
+        a_, m_ = avg.detach().requires_grad_(True), mx.detach().requires_grad_(True)
+        f1, f2 = fc1_w.detach().requires_grad_(True), fc2_w.detach().requires_grad_(True)
+        s_re = _clam_logits(a_, m_, f1, f2)
+        davg, dmax, dfc1, dfc2 = torch.autograd.grad(s_re, [a_, m_, f1, f2], ds)
+    _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg.contiguous()), _p(dmax.contiguous()), _p(arg), n, h,
+                                               w, c, _stream()), 'attn_tail_bwd_channel')
+    return du, dfc1, dfc2, dw7, dwc, dbc
+
+
+class _AttentionTail(Function):
+    @staticmethod
+    def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc):
+        _require_gpu(u, 'attention_tail')
+        u, skip = nhwc(u), nhwc(skip)
+        out, saved = _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc)
+        ctx.save_for_backward(u, fc1_w, fc2_w, w7, wc, *saved)
+        ctx.has_bias = bc is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, fc1_w, fc2_w, w7, wc, *saved = ctx.saved_tensors
+        g = nhwc(g)
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, ctx.has_bias,
+                                                       _skip_param_grads())
+        return du, g, dfc1, dfc2, dw7, dwc, dbc
+
+
+class _RabBlock(Function):
+    """Whole residual attention block (sradsgan.py:250-275) as ONE autograd node:
+         t = LeakyReLU_0.2(conv1(x)) ; u = conv2(t) ; out = conv1x1(SLAM(CLAM(u))) + x
+    Backward chains the fused kernels directly: conv2's dgrad applies conv1's activation mask in its
+    epilogue, conv1's dgrad adds the skip gradient in its epilogue -- no lrelu-backward pass, no
+    gradient-accumulation adds, 3 saved activations (x, t, u) instead of ~12."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
+        _require_gpu(x, 'rab_block')
+        x = nhwc(x)
+        t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
+        u = conv2d_fwd_raw(t, w2, b2, 1, 1)
+        out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc)
+        ctx.save_for_backward(x, t, u, w1, w2, fc1_w, fc2_w, w7, wc, *saved)
+        ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, u, w1, w2, fc1_w, fc2_w, w7, wc, *saved = ctx.saved_tensors
+        g = nhwc(g)
+        skip = _skip_param_grads()
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, ctx.has_b[2], skip)
+        dt = conv2d_dgrad_raw(du, w2, tuple(t.shape), 1, 1, None, t, 0.2)          # * LeakyReLU'(t)
+        dw2 = db2 = dw1 = db1 = None
+        if not skip:
+            dw2, db2 = conv2d_wgrad_raw(t, du, tuple(w2.shape), 1, 1, ctx.has_b[1])
+        dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g) if ctx.needs_input_grad[0] else None   # + skip gradient
+        if not skip:
+            dw1, db1 = conv2d_wgrad_raw(x, dt, tuple(w1.shape), 1, 1, ctx.has_b[0])
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
+
+
+def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
+    return _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc)
+
+
+def attention_tail_supported(u, fc1_w, w7, wc):
+    return (u.is_cuda and u.shape[1] == 64 and fc1_w.shape[0] <= 16 and tuple(w7.shape) == (1, 2, 7, 7)
+            and tuple(wc.shape[:2]) == (64, 64))
+
+
+def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc):
+    """conv1x1(SLAM(CLAM(u))) + bc + skip  for la_mode 'CA-SA', pool 'Avg|Max', addconv, C = 64."""
+    return _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc)
+
+
+# --------------------------------------------------------------------------------------------- #
 # attention / normalisation glue.  TRANSITIONAL: the functions below are still compositions of
 # torch device ops (ATen HIP kernels) around the HIP convs; each is being replaced by a fused HIP
 # kernel behind the same Python signature (DESIGN.md lists what is still on ATen).
@@ -339,7 +492,7 @@ def clam(x, fc1_w, fc2_w, pool_mode='Avg|Max'):
     if 'Avg' in pool_mode:
         logits = logits + _mlp_1x1(x.mean((2, 3), keepdim=True), fc1_w, fc2_w)
     if 'Max' in pool_mode:
-        logits = logits + _mlp_1x1(torch.nn.functional.adaptive_max_pool2d(x, 1), fc1_w, fc2_w)
+        logits = logits + _mlp_1x1(x.amax((2, 3), keepdim=True), fc1_w, fc2_w)
     return torch.sigmoid(logits) * x
 
 
@@ -376,22 +529,87 @@ def sgam(x, q, k, v, gamma):
     return gamma * out.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
 
 
+def _bn_reference_bwd(dy, x, y, gamma, eps, slope):
+    """First-order backward of train-mode BN(+LeakyReLU) written with differentiable torch ops; only
+    used to differentiate it once more (gradient penalty, sradsgan.py:621,639)."""
+    n = x.numel() // x.shape[1]
+    dz = dy if slope is None else dy * torch.where(y > 0, 1.0, float(slope))
+    mean = x.mean((0, 2, 3), keepdim=True)
+    var = x.var((0, 2, 3), unbiased=False, keepdim=True)
+    invstd = torch.rsqrt(var + eps)
+    xhat = (x - mean) * invstd
+    dbeta = dz.sum((0, 2, 3))
+    dgamma = (dz * xhat).sum((0, 2, 3))
+    dx = (gamma.view(1, -1, 1, 1) * invstd) * (dz - dbeta.view(1, -1, 1, 1) / n - xhat * dgamma.view(1, -1, 1, 1) / n)
+    return dx, dgamma, dbeta
+
+
+class _BNTrainBwd(Function):
+    @staticmethod
+    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope):
+        # NB: save the tensors autograd handed us (not layout-converted copies), or the second-order
+        # graph through x / dy would be cut
+        dyc, xc, yc = nhwc(dy), nhwc(x), nhwc(y)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        lib = _hip.lib()
+        dx = torch.empty_like(xc, memory_format=CL)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(lib.srhip_bn_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
+        _hip.check(lib.srhip_bn_train_bwd(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
+                                          _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, rows, c,
+                                          float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
+        ctx.eps, ctx.slope = eps, slope
+        ctx.save_for_backward(dy, x, y, gamma)
+        return dx, dgamma, dbeta
+
+    @staticmethod
+    def backward(ctx, ddx, ddgamma, ddbeta):
+        dy, x, y, gamma = ctx.saved_tensors
+        with torch.enable_grad():
+            dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
+            outs = _bn_reference_bwd(dy_, x_, y, g_, ctx.eps, ctx.slope)
+            pairs = [(o, d) for o, d in zip(outs, (ddx, ddgamma, ddbeta)) if d is not None]
+            gdy, gx, gg = torch.autograd.grad([o for o, _ in pairs], [dy_, x_, g_], [d for _, d in pairs],
+                                              allow_unused=True)
+        return gdy, gx, None, gg, None, None, None, None
+
+
+class _BNTrainFwd(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope):
+        _require_gpu(x, 'batch_norm')
+        xc = nhwc(x)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        lib = _hip.lib()
+        y = torch.empty_like(xc, memory_format=CL)
+        mean, invstd = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(lib.srhip_bn_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
+        _hip.check(lib.srhip_bn_train_fwd(_p(xc), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()),
+                                          _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws),
+                                          ws.numel() * 4, rows, c, float(eps), float(momentum), float(slope or 0.0),
+                                          int(slope is not None), _stream()), 'bn_train_fwd')
+        ctx.eps, ctx.slope = eps, slope
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
 def batch_norm_act(x, bn, slope=None):
-    """Train-mode BatchNorm2d + LeakyReLU (sradsgan.py:478-479); updates running stats like
-    nn.BatchNorm2d (momentum 0.1, unbiased running_var).  Twice differentiable."""
+    """Train-mode BatchNorm2d + LeakyReLU (sradsgan.py:478-479) on the fused HIP kernels; updates the
+    running statistics like nn.BatchNorm2d (momentum 0.1, unbiased running_var).  Twice differentiable."""
     if not bn.training:
         raise NotImplementedError('the reference never puts the discriminator in eval() (SURVEY a11)')
-    n = x.numel() // x.shape[1]
-    mean = x.mean((0, 2, 3))
-    var = x.var((0, 2, 3), unbiased=False)
+    y = _BNTrainFwd.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
     with torch.no_grad():
-        m = bn.momentum
-        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
         bn.num_batches_tracked += 1
-    inv = torch.rsqrt(var + bn.eps)
-    y = (x - mean.view(1, -1, 1, 1)) * (inv * bn.weight).view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
-    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+    return y
 
 
 def max_pool2x2(x):

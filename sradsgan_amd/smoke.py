@@ -20,6 +20,6 @@ def run(device):
     # WGAN-GP double backward) on both paths with identical deterministic weights/inputs
     worst, wdiff = train_parity(device, 'smoke', 2, 1, 2, 8, 4, 2)
     torch.cuda.synchronize()
-    print('smoke: max |scalar diff| vs oracle = %.3e, max rel weight diff = %.3e' % (worst, wdiff))
+    print('smoke: max |scalar diff| vs oracle = %.3e, weight score = %.3e' % (worst, wdiff))
     if not (worst < 1e-3 and wdiff < 5e-3):
         raise AssertionError('smoke: HIP path differs from the oracle (%.3e, %.3e)' % (worst, wdiff))

@@ -21,6 +21,7 @@ Differences from the reference that do not change results (DESIGN.md "restructur
   * losses stay on the device; nothing calls .item() inside the step (the reference syncs 4x, :898).
 """
 import ctypes
+import os
 
 import torch
 
@@ -116,8 +117,13 @@ class TrainStep:
     def _capture(self, imgs_lr, imgs_hr, alpha):
         self._static = dict(lr=imgs_lr.clone(), hr=imgs_hr.clone(), alpha=alpha.clone())
         self._graph = torch.cuda.CUDAGraph()
+        dump = os.environ.get('SRHIP_GRAPH_DUMP')
+        if dump:
+            self._graph.enable_debug_mode()
         with torch.cuda.graph(self._graph):
             self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
+        if dump:
+            self._graph.debug_dump(dump)
 
     def __call__(self, imgs_lr, imgs_hr, alpha):
         self._calls += 1

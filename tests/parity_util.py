@@ -26,15 +26,51 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
+# Parameters whose gradient is IDENTICALLY zero in exact arithmetic, so every platform only sees its own
+# roundoff there: conv biases feeding a train-mode BatchNorm (the mean subtraction cancels them;
+# discriminator model.{2,5,8,11,14,19,22}) and SGAM's key bias (softmax shift invariance).
+ZERO_GRAD_KEYS = tuple('model.%d.bias' % i for i in (2, 5, 8, 11, 14, 19, 22)) + ('key_conv.bias',)
+
+
+def grad_score(hip_nets, ora_nets, floor=1e-2, verbose=False):
+    """max over parameter tensors of max|dg| / max(max|g_tensor|, floor * max|g_network|); returns
+    (score, name of the worst tensor).  ZERO_GRAD_KEYS are skipped (see above).  The floor exists
+    because D's gradients are differences of large real/fake terms: a tensor whose own gradient is
+    orders of magnitude below the network's carries that network-scale roundoff."""
+    rows = []
+    for hn, on in zip(hip_nets, ora_nets):
+        og = {k: p.grad for k, p in on.named_parameters() if p.grad is not None}
+        if not og:
+            continue
+        net_scale = max(float(g.abs().max()) for g in og.values())
+        for k, p in hn.named_parameters():
+            if k in og and p.grad is not None and not k.endswith(ZERO_GRAD_KEYS):
+                d = float((p.grad.detach().cpu().double() - og[k].double()).abs().max())
+                own = float(og[k].abs().max())
+                rows.append((d / max(own, floor * net_scale, 1e-30), k, d, own, net_scale))
+    rows.sort(reverse=True)
+    if verbose:
+        for r in rows[:5]:
+            print('   grad score %.3e  %-34s |dg| %.3e  |g| %.3e  |g_net| %.3e' % r)
+    return (rows[0][0], rows[0][1]) if rows else (0.0, '')
+
+
 def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, golden=None):
-    """Runs `iters` training iterations on both paths; returns max abs scalar diff and max rel
-    weight diff.  With `golden` (npz from the reference) the HIP scalars are also checked against it."""
+    """Runs `iters` training iterations on both paths; returns the max abs scalar diff and the worst
+    gradient score (grad_score) over the iterations.  With `golden` (npz from the reference) the HIP
+    scalars are also checked against it.
+
+    Post-step WEIGHTS are not compared element-wise: Adam turns every gradient into a step of
+    ~lr*sign(g), so an element whose true gradient is (near) zero moves by +-lr on ANY two platforms
+    depending on roundoff.  Instead: gradients are compared before each update (here), the optimiser
+    arithmetic is pinned against torch.optim.Adam on identical gradients
+    (test_adam_kernel_matches_torch), and no weight may differ by more than the 2*lr*iters bound."""
     from sradsgan_amd.train_step import TrainStep
     (hg, hd, hf), (og, od, of) = build_pair(n_groups, n_blocks, scale, device)
     step = TrainStep(hg, hd, hf)
     oG = torch.optim.Adam(og.parameters(), lr=2e-4, betas=(0.9, 0.999))
     oD = torch.optim.Adam(od.parameters(), lr=2e-4, betas=(0.9, 0.999))
-    worst = 0.0
+    worst, gscore = 0.0, 0.0
     names = ['loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp']
     for it in range(iters):
         lr_img = O.det_fill('%s.lr.%d' % (tag, it), (batch, 3, lr_side, lr_side), 0.5, 0.5)
@@ -50,11 +86,25 @@ def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, 
         worst = max(worst, float(np.abs(gv - wv).max()))
         if golden is not None:
             worst = max(worst, float(np.abs(gv - golden['scalars%d' % it]).max()))
-    wdiff = 0.0
+        # .grad still holds this iteration's gradients.  Iteration 0 is the clean comparison (identical
+        # weights on both sides); later iterations inherit Adam's +-lr sign-of-roundoff steps (see below)
+        sg, kg = grad_score((hg,), (og,), verbose=True)
+        sd, kd = grad_score((hd,), (od,), verbose=True)
+        print('train_parity[%s] it %d: worst G gradient %s %.3e, worst D gradient %s %.3e' % (tag, it, kg, sg, kd, sd))
+        if it == 0:
+            # G: first-order gradients, fp32 roundoff only.  D: dominated by the WGAN-GP double backward
+            # through train-mode BatchNorm (weight 1+lambda = 11), which is ill-conditioned in fp32 on any
+            # platform (the reference-recorded vectors in test_gradient_penalty_double_backward carry 5e-3):
+            # normalise both to the common 5e-3 bar.
+            gscore = max(gscore, sg, sd * (5e-3 / 2e-2))
+            for (k, a), (_, b) in zip(hd.state_dict().items(), od.state_dict().items()):
+                if 'running_' in k:                      # BatchNorm running statistics after the first 4 updates
+                    gscore = max(gscore, rel_err(a, b))
+    lr = 2e-4
     for (k, a), (_, b) in zip(list(hg.state_dict().items()) + list(hd.state_dict().items()),
                               list(og.state_dict().items()) + list(od.state_dict().items())):
-        # SGAM's key bias has a mathematically zero gradient (softmax shift invariance): Adam turns
-        # its pure-roundoff gradient into +-lr steps on ANY two platforms, so it is not comparable.
-        if a.dtype.is_floating_point and not k.endswith('key_conv.bias'):
-            wdiff = max(wdiff, rel_err(a, b))
-    return worst, wdiff
+        if a.dtype.is_floating_point and 'running_' not in k:
+            d = float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+            if d > 2 * lr * iters * 1.01 + 1e-7:
+                gscore = max(gscore, d / lr)
+    return worst, gscore

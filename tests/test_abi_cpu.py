@@ -37,13 +37,15 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 def test_pure_host_entry_points(lib):
     assert lib.srhip_abi_version() >= 1
-    assert lib.srhip_packed_ld(64) == 64 and lib.srhip_packed_ld(3) == 32 and lib.srhip_packed_ld(65) == 96
+    assert lib.srhip_packed_elems(256, 64, 3, 3, 0) == 256 * 64 * 9          # fast n-major layout
+    assert lib.srhip_packed_elems(64, 3, 3, 3, 0) == 27 * 64                 # generic k-major, ld = 64
+    assert lib.srhip_packed_elems(3, 64, 3, 3, 0) == 3 * 64 * 9 and lib.srhip_packed_elems(3, 64, 3, 3, 1) == 27 * 64
     assert lib.srhip_colsum_workspace(1000, 64) >= 64 * 4
     assert lib.srhip_conv2d_wgrad_workspace(2, 54, 54, 64, 256, 3, 3, 1, 1) >= 256 * 576 * 4
 
 
 def test_argument_errors_do_not_cross_as_exceptions(lib):
-    rc = lib.srhip_conv2d_fwd(None, None, None, None, None, None, 1, 4, 4, 3, 3, 3, 3, 1, 1, 3, 3, 3, 0.0, 0, None)
+    rc = lib.srhip_conv2d_fwd(None, None, None, None, None, None, None, 1, 4, 4, 3, 3, 3, 3, 1, 1, 3, 3, 3, 0.0, 0, None)
     assert rc == -1 and b'null tensor' in lib.srhip_last_error()
     rc = lib.srhip_adam_step(None, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0.0, None)
     assert rc == -1

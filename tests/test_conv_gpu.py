@@ -115,3 +115,74 @@ def test_pixel_shuffle_index_exact(golden):
         src = torch.arange(c * r * r * h * w, dtype=torch.float32).reshape(1, c * r * r, h, w)
         got = ops.pixel_shuffle_act(src.to(dev), r, None).cpu().to(torch.int64).numpy()
         assert np.array_equal(got[:, :2], tab['r%d' % r])
+
+
+def test_stride2_dgrad_phase_decomposition_and_wgrad_bias():
+    """Fast path specifics: stride-2 backward-data as 4 phase GEMMs (odd and even sizes), bias gradient
+    emitted by the wgrad kernel, channel/row scaling folded into the conv operands."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    for (n, cin, h, w, cout) in [(2, 64, 27, 27, 64), (3, 128, 16, 20, 64), (1, 64, 7, 9, 128)]:
+        g = torch.Generator().manual_seed(n * h + w)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        b = torch.randn(cout, generator=g)
+        xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = F.conv2d(xr, wr, br, 2, 1)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xg, wg, bg = (t.clone().to(dev).requires_grad_() for t in (x, wt, b))
+        yg = ops.conv2d(xg, wg, bg, 2, 1)
+        yg.backward(dy.to(dev))
+        assert _rel(yg, yr) < TOL and _rel(xg.grad, xr.grad) < TOL
+        assert _rel(wg.grad, wr.grad) < TOL and _rel(bg.grad, br.grad) < TOL
+
+
+def test_conv_operand_scaling():
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w = 3, 64, 9, 11
+    x, res = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    wt, b = torch.randn(64, 64, 1, 1, generator=g) * 0.1, torch.randn(64, generator=g)
+    s, m = torch.rand(n, c, generator=g), torch.rand(n, 1, h, w, generator=g)
+    z = x * s.view(n, c, 1, 1) * m
+    ref = F.conv2d(z, wt, b) + res
+    got = ops.conv2d_fwd_raw(x.to(dev), wt.to(dev), b.to(dev), 1, 0, None, res.to(dev),
+                             m.permute(0, 2, 3, 1).reshape(-1).contiguous().to(dev), s.to(dev))
+    assert _rel(got, ref) < TOL
+    dy = torch.randn(ref.shape, generator=g)
+    dw_ref = torch.nn.grad.conv2d_weight(z, wt.shape, dy)
+    dw, db = ops.conv2d_wgrad_raw(x.to(dev), dy.to(dev), tuple(wt.shape), 1, 0, True,
+                                  m.permute(0, 2, 3, 1).reshape(-1).contiguous().to(dev), s.to(dev))
+    assert _rel(dw, dw_ref) < TOL and _rel(db, dy.sum((0, 2, 3))) < TOL
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 9, 7), (2, 128, 14, 14), (3, 512, 5, 5)])
+def test_batch_norm_lrelu_fwd_bwd_double_bwd(shape):
+    """Fused train-mode BatchNorm2d+LeakyReLU (sradsgan.py:478-479) vs torch CPU, including the running
+    statistics and the second-order path the gradient penalty takes (:621,:639)."""
+    from sradsgan_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g) * 0.7 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    dy = torch.randn(n, c, h, w, generator=g)
+
+    def run(dev, fused):
+        bn = torch.nn.BatchNorm2d(c)
+        with torch.no_grad():
+            bn.weight.copy_(gamma), bn.bias.copy_(beta)
+        bn.to(dev).train()
+        xx = x.clone().to(dev).requires_grad_()
+        y = ops.batch_norm_act(xx, bn, 0.2) if fused else F.leaky_relu(bn(xx), 0.2)
+        (gx,) = torch.autograd.grad(y, xx, dy.to(dev), create_graph=True)
+        pen = ((gx.norm(2, 1) - 1) ** 2).mean() + y.mean()
+        pen.backward()
+        return (y, gx, xx.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+
+    ref = run(torch.device('cpu'), False)
+    got = run(torch.device('cuda:0'), True)
+    for name, a, b in zip(('y', 'dx', 'ddx', 'dgamma', 'dbeta', 'running_mean', 'running_var'), got, ref):
+        assert _rel(a, b) < 2e-4, name
+    assert int(got[7]) == int(ref[7]) == 1

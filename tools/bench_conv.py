@@ -34,6 +34,6 @@ for name, cin, h, w, cout, k, st, p in shapes:
     fl = 2.0 * y.numel() * cin * k * k
     tf = timeit(lambda: ops.conv2d_fwd_raw(x, wt, b, st, p, 0.2))
     td = timeit(lambda: ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), st, p))
-    tw = timeit(lambda: ops.conv2d_wgrad_raw(x, dy, tuple(wt.shape), st, p))
+    tw = timeit(lambda: ops.conv2d_wgrad_raw(x, dy, tuple(wt.shape), st, p, True))
     print('%-20s B=%d  %.2f GF | fwd %.3f ms %.1f TF | dgrad %.3f ms %.1f TF | wgrad %.3f ms %.1f TF' % (
         name, B, fl / 1e9, tf, fl / tf / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9), flush=True)
