@@ -8,6 +8,8 @@ using namespace srhip;
 namespace srhip {
 extern int g_fast_cfg;
 extern int g_wgrad_cfg;
+extern int g_fast_dynlds;
+extern int g_fast_ablate;
 }
 
 extern "C" {
@@ -20,6 +22,14 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 1) {
     g_wgrad_cfg = value;
+    return SRHIP_OK;
+  }
+  if (key == 2) {
+    g_fast_dynlds = value;
+    return SRHIP_OK;
+  }
+  if (key == 3) {
+    g_fast_ablate = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

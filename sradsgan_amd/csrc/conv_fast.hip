@@ -24,6 +24,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FBK = 16;            // K values per chunk
 constexpr int FLS = FBK + 4;       // LDS row stride in floats (80 B: b128 reads hit all 64 banks once)
 constexpr unsigned F_OOB = 0x80000000u;
+int g_fast_ablate = 0;   // srhip_debug_set(3, bits): 0x100 = no in-loop loads, 0x200 = no barrier (timing only, wrong results)
 
 struct FastGeom {
   int N, Hs, Ws, C, lds;           // source tensor, NHWC, row stride lds (elements)
@@ -193,9 +194,10 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
     load_tiles();
     store_tiles(0);
     __syncthreads();
+    const bool abl_noload = (g.flags & 0x100) != 0, abl_nobar = (g.flags & 0x200) != 0;   // timing ablations only
     for (int kc = 0; kc < nk; ++kc) {
-      const int stage = kc & 1;
-      if (kc + 1 < nk) load_tiles();
+      const int stage = abl_noload ? 0 : (kc & 1);
+      if (kc + 1 < nk && !abl_noload) load_tiles();
       const float* a = lds + stage * STAGE + (wm * WTM + l31) * LS + khalf * 4;
       const float* b = lds + stage * STAGE + BM * LS + (wn * WTN + l31) * LS + khalf * 4;
       float4 af[2][TM], bf[2][TN];
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
 #pragma unroll
           for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[cur][t].w, bf[cur][u].w, acc[t][u]);
       }
-      if (kc + 1 < nk) store_tiles(stage ^ 1);
-      __syncthreads();
+      if (kc + 1 < nk && !abl_noload) store_tiles(stage ^ 1);
+      if (!abl_nobar) __syncthreads();
     }
   }
 
@@ -260,6 +262,225 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
         if (g.flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
         if (g.flags & SRHIP_EPI_ACTMASK) v = actmask[dpix * g.ldd + n] > 0.f ? v : v * g.slope;
         if (g.flags & SRHIP_EPI_RESIDUAL) v += residual[dpix * g.ldr + n];
+        float* o = dst + dpix * g.ldd + n;
+        if (g.accumulate) v += *o;
+        *o = v;
+      }
+    }
+  }
+}
+
+// ================================================================================================ //
+// fprop / dgrad, LDS-DMA variant: tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR
+// staging, no ds_write), 3-stage ring, prefetch distance 2, ONE raw s_barrier per K chunk and a
+// counted s_waitcnt vmcnt (the loads of the next chunk stay in flight across the barrier).
+//   * the DMA writes lane-linear (wave base + lane*16 B), so an LDS row is 64 B unpadded and the
+//     bank spread comes from an XOR swizzle applied on the SOURCE side: 16-byte slot (row, s) holds
+//     global quad q = s ^ ((row>>2)&3); fragment reads apply the same involution => conflict-free
+//     ds_read_b128 (every 16-lane service group covers all 16 slots of a 256 B bank row once);
+//   * padding / stride holes: lanes whose tap falls outside the image DMA from a 16-byte zero block;
+//   * the DMA and its wait are inline asm (hipcc would otherwise drain vmcnt(0) before every ds_read
+//     that may alias an in-flight LDS-DMA); the fragment reads stay ordinary loads and are ordered
+//     behind the asm wait + barrier by their "memory" clobbers;
+//   * EPI >= 0 fixes the epilogue flags at compile time (no per-element branches); EPI < 0 = dynamic.
+// ================================================================================================ //
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ inline void lds_dma16(const float* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst_uniform)
+      : "memory");
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restrict__ src, const float* __restrict__ wt,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ residual,
+                                                             const float* __restrict__ rowscale,
+                                                             const float* __restrict__ actmask,
+                                                             float* __restrict__ dst, FastGeom g, int nblk_m,
+                                                             int nblk_n) {
+  constexpr int WM = 2, WN = 2, BK = 16;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 64, BI = BN / 64;            // DMA instructions per wave per chunk (16 rows each)
+  constexpr int STAGE_B = (BM + BN) * 64;              // bytes per stage (64 B per row)
+  __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
+  const int tile_n = tile % nblk_n, tile_m = tile / nblk_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  // ---- DMA bookkeeping: this lane feeds slot (row, s = lane&3) of rows wave*16*AI + 16*i + (lane>>2) ----
+  const int OHOW = g.OH * g.OW;
+  int abase[AI];
+  unsigned amask[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = wave * 16 * AI + 16 * i + (lane >> 2);
+    const int q = (lane & 3) ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    abase[i] = 0;
+    amask[i] = 0;
+    if (m < g.M) {
+      const int n = m / OHOW;
+      const int rem = m - n * OHOW;
+      const int oh = rem / g.OW;
+      const int ow = rem - oh * g.OW;
+      const int sh0 = oh * g.ss, sw0 = ow * g.ss;
+      abase[i] = ((n * g.Hs + sh0) * g.Ws + sw0) * g.lds + q * 4;
+      unsigned mk = 0;
+      for (int th = 0; th < g.TH; ++th) {
+        const int sh = sh0 + g.dh0 + th * g.dhs;
+        for (int tw = 0; tw < g.TW; ++tw) {
+          const int sw = sw0 + g.dw0 + tw * g.dws;
+          if (sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws) mk |= 1u << (th * g.TW + tw);
+        }
+      }
+      amask[i] = mk;
+    }
+  }
+  int bbase[BI];
+  bool bval[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int row = wave * 16 * BI + 16 * j + (lane >> 2);
+    const int q = (lane & 3) ^ ((row >> 2) & 3);
+    const int n = n0 + row;
+    bval[j] = n < g.K;
+    bbase[j] = n * g.ldw + q * 4;
+  }
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * 16 * AI * 64);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + BM * 64 + wave * 16 * BI * 64);
+
+  const int CC = g.C / BK;
+  const int nk = g.TH * g.TW * CC;
+  int th = 0, tw = 0, cc = 0;
+  auto issue = [&](int stage) {
+    const int tapoff = ((g.dh0 + th * g.dhs) * g.Ws + (g.dw0 + tw * g.dws)) * g.lds + cc * BK;
+    const int wk = ((g.kh0 + th * g.khs) * g.KW + (g.kw0 + tw * g.kws)) * g.C + cc * BK;
+    const int bit = th * g.TW + tw;
+    const unsigned so = stage * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const float* p = ((amask[i] >> bit) & 1u) ? src + (long)(abase[i] + tapoff) : g_zero16;
+      lds_dma16(p, a_dst + so + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
+      lds_dma16(p, b_dst + so + j * 1024);
+    }
+    if (++cc == CC) {
+      cc = 0;
+      if (++tw == g.TW) {
+        tw = 0;
+        ++th;
+      }
+    }
+  };
+
+  // ---- fragment addresses (bytes inside a stage): slot (row, q ^ ((row>>2)&3)), q = ks*2 + khalf ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  int aoff[TM], boff[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 32 + l31;
+    aoff[t] = row * 64 + ((khalf ^ ((row >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int row = wn * WTN + u * 32 + l31;
+    boff[u] = BM * 64 + row * 64 + ((khalf ^ ((row >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  if (nk > 0) {
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0, nstage = 2;                       // nstage: where chunk kc+2 goes
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");   // chunk kc landed; kc+1 may still fly
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // everyone's chunk kc visible; everyone done with chunk kc-1
+      asm volatile("" ::: "memory");
+      if (kc + 2 < nk) issue(nstage);
+      const char* sb = lds + stage * STAGE_B;
+      float4 af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) af[0][t] = *reinterpret_cast<const float4*>(sb + aoff[t]);
+#pragma unroll
+      for (int u = 0; u < TN; ++u) bf[0][u] = *reinterpret_cast<const float4*>(sb + boff[u]);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ 32));
+#pragma unroll
+      for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ 32));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].x, bf[ks][u].x, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].y, bf[ks][u].y, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].z, bf[ks][u].z, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].w, bf[ks][u].w, acc[t][u]);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+      nstage = nstage == 2 ? 0 : nstage + 1;
+    }
+  }
+
+  // ---- epilogue ----
+  const int flags = EPI >= 0 ? EPI : g.flags;
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (m >= g.M) continue;
+      size_t dpix = (size_t)m;
+      if (!g.dst_identity) {
+        const int n = m / OHOW;
+        const int rem = m - n * OHOW;
+        const int oh = rem / g.OW;
+        const int ow = rem - oh * g.OW;
+        dpix = ((size_t)n * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
+      }
+      const float rsc = (flags & SRHIP_EPI_ROWSCALE) ? rowscale[dpix] : 1.f;
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int n = n0 + wn * WTN + u * 32 + l31;
+        if (n >= g.K) continue;
+        float v = acc[t][u][r];
+        if (flags & SRHIP_EPI_ROWSCALE) v *= rsc;
+        if (flags & SRHIP_EPI_BIAS) v += bias[n];
+        if (flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
+        if (flags & SRHIP_EPI_ACTMASK) v = actmask[dpix * g.ldd + n] > 0.f ? v : v * g.slope;
+        if (flags & SRHIP_EPI_RESIDUAL) v += residual[dpix * g.ldr + n];
         float* o = dst + dpix * g.ldd + n;
         if (g.accumulate) v += *o;
         *o = v;
@@ -534,12 +755,13 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
   return check_launch("fast_pack_weight");
 }
 
+int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_fast(const float* src, const float* wt, const float* bias, const float* residual,
                        const float* rowscale, const float* chanscale, const float* actmask, float* dst,
                        const FastGeom& g, hipStream_t st) {
   const int nbm = cdiv(g.M, BM), nbn = cdiv(g.K, BN);
-  hipLaunchKernelGGL((fast_conv_kernel<BM, BN, WM, WN, BK>), dim3(nbm * nbn), dim3(WM * WN * 64), 0, st, src, wt, bias,
+  hipLaunchKernelGGL((fast_conv_kernel<BM, BN, WM, WN, BK>), dim3(nbm * nbn), dim3(WM * WN * 64), g_fast_dynlds, st, src, wt, bias,
                      residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
   return check_launch("fast_conv");
 }
@@ -554,6 +776,36 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
 #define SRHIP_LF(BM_, BN_, WM_, WN_, BK_) \
   return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
   if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
+  // LDS-DMA kernels (g_fast_cfg 20 forces them off): no A-operand scaling, ablation flags or accumulate variants needed
+  const int eflags = g.flags & 0xff;
+  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(eflags & SRHIP_EPI_CHANSCALE) && !(g.flags & 0x300) && g.K >= 64) {
+    const int nbm = cdiv(g.M, 128);
+    const bool wide = g.K >= 128 && (long)nbm * cdiv(g.K, 128) >= 512;
+    const long b64 = (long)nbm * cdiv(g.K, 64);
+    if (wide || b64 >= 512) {
+#define SRHIP_LD(BN_, EPI_)                                                                                        \
+  do {                                                                                                             \
+    const int nbn = cdiv(g.K, BN_);                                                                                \
+    hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src, \
+                       wt, bias, residual, rowscale, actmask, dst, g, nbm, nbn);                                   \
+    return check_launch("fast_conv_dma");                                                                          \
+  } while (0)
+#define SRHIP_LDE(BN_)                                                  \
+  do {                                                                  \
+    if (g.accumulate) SRHIP_LD(BN_, -1);                                \
+    if (eflags == 0) SRHIP_LD(BN_, 0);                                  \
+    if (eflags == SRHIP_EPI_BIAS) SRHIP_LD(BN_, 1);                     \
+    if (eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_LD(BN_, 3); \
+    if (eflags == SRHIP_EPI_ACTMASK) SRHIP_LD(BN_, 32);                 \
+    if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LD(BN_, 4);                 \
+    SRHIP_LD(BN_, -1);                                                  \
+  } while (0)
+      if (wide) SRHIP_LDE(128);
+      SRHIP_LDE(64);
+#undef SRHIP_LDE
+#undef SRHIP_LD
+    }
+  }
   const bool k32 = g.C % 32 == 0;
   if (g_fast_cfg == 1 && g.K >= 128 && k32) SRHIP_LF(128, 128, 2, 2, 32);
   if (g_fast_cfg == 2 && g.K >= 128) SRHIP_LF(64, 128, 1, 4, 16);
@@ -593,7 +845,7 @@ int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, cons
   g.TH = kh; g.TW = kw; g.dh0 = -pad; g.dhs = 1; g.dw0 = -pad; g.dws = 1;
   g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1; g.KW = kw;
   g.Hd = g.OH; g.Wd = g.OW; g.dsd = 1; g.ph = 0; g.pw = 0; g.ldd = ldy; g.K = cout;
-  g.ldw = kh * kw * cin; g.ldr = ldr; g.slope = slope; g.flags = flags; g.accumulate = 0; g.dst_identity = 1;
+  g.ldw = kh * kw * cin; g.ldr = ldr; g.slope = slope; g.flags = flags | g_fast_ablate; g.accumulate = 0; g.dst_identity = 1;
   SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.src_bytes), "conv2d_fwd: source tensor >= 2 GiB");
   g.w_bytes = (unsigned)((long)cout * g.ldw * 4);
   return run_fast(x, packed, bias, residual, rowscale, chanscale, nullptr, y, g, st);
