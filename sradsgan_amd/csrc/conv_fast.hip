@@ -522,11 +522,23 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict
   const int tid = threadIdx.x;
   const int ntn = (g.Ktot + BN - 1) / BN;
   const int ntm = (g.K + BM - 1) / BM;
-  int bid = blockIdx.x;
-  const int tile_n = bid % ntn;
-  bid /= ntn;
-  const int tile_m = bid % ntm;
-  const int split = bid / ntm;
+  // XCD-aware order: every tile (tile_m, tile_n) of one pixel split runs on the same XCD (blocks b, b+8,
+  // b+16, ... share an L2), so a dy / x chunk is fetched from HBM once per split instead of once per tile
+  int tile_n, tile_m, split;
+  {
+    const int tps = ntm * ntn;
+    int bid = blockIdx.x;
+    if (g.nsplit % 8 == 0) {
+      const int j = bid >> 3;
+      split = (j / tps) * 8 + (bid & 7);
+      bid = j % tps;
+    } else {
+      split = bid / tps;
+      bid -= split * tps;
+    }
+    tile_n = bid % ntn;
+    tile_m = bid / ntn;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.x_bytes, 0x00020000);
@@ -692,30 +704,199 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict
   }
 }
 
-// partial[s][co][(tap,ci)] --sum over s--> dw[co][ci][kh][kw];  bias_partial[s][co] --> db[co]
-__global__ void fast_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
-                                         float* __restrict__ dw, float* __restrict__ db, int nsplit, int cout,
-                                         int cin, int khkw, int ktot) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = cout * ktot;
-  if (idx < total) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= nsplit; i += 4) {
-      s0 += partial[(size_t)(i + 0) * total + idx];
-      s1 += partial[(size_t)(i + 1) * total + idx];
-      s2 += partial[(size_t)(i + 2) * total + idx];
-      s3 += partial[(size_t)(i + 3) * total + idx];
+// ---- wgrad, LDS-DMA variant: same ring / counted-vmcnt structure as fast_conv_dma_kernel.  Both
+// operands are pixel-major, so a stage is simply [16 pixels][BM] + [16 pixels][BN] floats, written
+// lane-linear by the DMA and read back as conflict-free ds_read_b32 (consecutive dwords) -- no swizzle.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial,
+                                                              float* __restrict__ bias_partial, WgradGeom g) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AI = BM / 64, BI = BN / 64;              // DMA instructions per wave per chunk
+  constexpr int ALR = BM / 4, BLR = BN / 4;              // lanes per pixel row
+  constexpr int ARPI = 64 / ALR, BRPI = 64 / BLR;        // pixel rows per DMA instruction
+  constexpr int STAGE_B = (BM + BN) * FBK * 4;
+  __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = (g.Ktot + BN - 1) / BN;
+  const int ntm = (g.K + BM - 1) / BM;
+  // XCD-aware order: every tile (tile_m, tile_n) of one pixel split runs on the same XCD (blocks b, b+8,
+  // b+16, ... share an L2), so a dy / x chunk is fetched from HBM once per split instead of once per tile
+  int tile_n, tile_m, split;
+  {
+    const int tps = ntm * ntn;
+    int bid = blockIdx.x;
+    if (g.nsplit % 8 == 0) {
+      const int j = bid >> 3;
+      split = (j / tps) * 8 + (bid & 7);
+      bid = j % tps;
+    } else {
+      split = bid / tps;
+      bid -= split * tps;
     }
-    for (; i < nsplit; ++i) s0 += partial[(size_t)i * total + idx];
-    const int co = idx / ktot, kcol = idx - co * ktot;
-    const int tap = kcol / cin, ci = kcol - tap * cin;
-    dw[((size_t)co * cin + ci) * khkw + tap] = (s0 + s1) + (s2 + s3);
-  } else if (db != nullptr && idx < total + cout) {
-    const int co = idx - total;
-    float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += bias_partial[(size_t)i * cout + co];
-    db[co] = s;
+    tile_n = bid % ntn;
+    tile_m = bid / ntn;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  const int c_begin = split * g.chunks_per_split;
+  const int nchunks_total = (g.P + FBK - 1) / FBK;
+  const int c_end = min(c_begin + g.chunks_per_split, nchunks_total);
+  const int nk = c_end - c_begin;
+
+  // A (dy): this lane feeds pixel row arow[i], channels m0 + acol*4 ..
+  const int acol = lane % ALR;
+  const bool a_colok = (m0 + acol * 4) < g.K;
+  int arow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) arow[i] = (wave * AI + i) * ARPI + lane / ALR;
+  // B (x window): pixel row brow[j], columns kcol..kcol+3 of ONE tap
+  const int bcolq = lane % BLR;
+  const int kcol = n0 + bcolq * 4;
+  const bool b_colok = kcol < g.Ktot;
+  const int tap = kcol / g.C, ci0 = kcol - tap * g.C;
+  const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  int bn[BI], bho[BI], bwo[BI];
+  const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int p = c_begin * FBK + (wave * BI + j) * BRPI + lane / BLR;
+    bn[j] = p / HoWo;
+    const int rem = p - bn[j] * HoWo;
+    bho[j] = rem / g.Wo;
+    bwo[j] = rem - bho[j] * g.Wo;
+  }
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * AI * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + BM * FBK * 4 + wave * BI * 1024);
+
+  int kc_issue = c_begin;
+  auto issue = [&](int stage) {
+    const unsigned so = stage * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int p = kc_issue * FBK + arow[i];
+      const float* ptr = (p < g.P && a_colok) ? dy + ((long)p * g.ldy + m0 + acol * 4) : g_zero16;
+      lds_dma16(ptr, a_dst + so + i * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int hi = bho[j] * g.stride - g.pad + kh, wi = bwo[j] * g.stride - g.pad + kw;
+      const bool ok = b_colok && bn[j] < g.N && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+      const float* ptr = ok ? x + ((long)((bn[j] * g.H + hi) * g.W + wi) * g.ldx + ci0) : g_zero16;
+      lds_dma16(ptr, b_dst + so + j * 1024);
+      bwo[j] += FBK;
+      while (bwo[j] >= g.Wo) {
+        bwo[j] -= g.Wo;
+        if (++bho[j] == g.Ho) {
+          bho[j] = 0;
+          ++bn[j];
+        }
+      }
+    }
+    ++kc_issue;
+  };
+
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = bias_partial != nullptr && tile_n == 0 && tid < BM;
+
+  if (nk > 0) {
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0, nstage = 2;
+    for (int kc = 0; kc < nk; ++kc) {
+      if (kc + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kc + 2 < nk) issue(nstage);
+      const float* a = reinterpret_cast<const float*>(lds + stage * STAGE_B) + khalf * BM + wm * WTM + l31;
+      const float* b = reinterpret_cast<const float*>(lds + stage * STAGE_B) + FBK * BM + khalf * BN + wn * WTN + l31;
+#pragma unroll
+      for (int kk = 0; kk < FBK / 2; ++kk) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * BM + t * 32];
+#pragma unroll
+        for (int u = 0; u < TN; ++u) bv[u] = b[kk * 2 * BN + u * 32];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(av[t], bv[u], acc[t][u]);
+      }
+      if (want_bias) {
+        const float* col = reinterpret_cast<const float*>(lds + stage * STAGE_B) + tid;
+#pragma unroll
+        for (int r = 0; r < FBK; ++r) bsum += col[r * BM];
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+      nstage = nstage == 2 ? 0 : nstage + 1;
+    }
+  }
+
+  float* out = partial + (size_t)split * g.K * g.Ktot;
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int n = n0 + wn * WTN + u * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (m < g.K && n < g.Ktot) out[(size_t)m * g.Ktot + n] = acc[t][u][r];
+      }
+  }
+  if (want_bias && m0 + tid < g.K) bias_partial[(size_t)split * g.K + m0 + tid] = bsum;
+}
+
+// partial[s][co][(tap,ci)] --sum over s--> dw[co][ci][kh][kw];  bias_partial[s][co] --> db[co]
+__global__ __launch_bounds__(256) void fast_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                 const float* __restrict__ bias_partial,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int nsplit, int cout, int cin, int khkw, int ktot) {
+  // 64 outputs per block x 4 split lanes; each lane keeps 4 loads in flight, LDS combines the lanes
+  __shared__ float red[256];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int total = cout * ktot;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < total) {
+    int i = sub;
+    for (; i + 12 < nsplit; i += 16) {
+      s0 += partial[(size_t)(i + 0) * total + e];
+      s1 += partial[(size_t)(i + 4) * total + e];
+      s2 += partial[(size_t)(i + 8) * total + e];
+      s3 += partial[(size_t)(i + 12) * total + e];
+    }
+    for (; i < nsplit; i += 4) s0 += partial[(size_t)i * total + e];
+  } else if (db != nullptr && e < total + cout) {
+    const int co = e - total;
+    for (int i = sub; i < nsplit; i += 4) s0 += bias_partial[(size_t)i * cout + co];
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0) {
+    const int t = threadIdx.x;
+    const float v = (red[t] + red[t + 64]) + (red[t + 128] + red[t + 192]);
+    if (e < total) {
+      const int co = e / ktot, kcol = e - co * ktot;
+      const int tap = kcol / cin, ci = kcol - tap * cin;
+      dw[((size_t)co * cin + ci) * khkw + tap] = v;
+    } else if (db != nullptr && e < total + cout) {
+      db[e - total] = v;
+    }
   }
 }
 
@@ -892,13 +1073,13 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
 struct FastWgradPlan {
   int bm, bn, nsplit, chunks_per_split;
 };
-int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128
+int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, +10: register-staged kernel
 static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
   FastWgradPlan p;
   p.bm = cout > 64 ? 128 : 64;
-  p.bn = ktot >= 128 ? 128 : 64;
-  if (g_wgrad_cfg == 1) p.bn = 64;
-  if (g_wgrad_cfg == 2) p.bn = 128;
+  p.bn = (ktot % 128 == 0) ? 128 : 64;            // Ktot = 9*64 tiles exactly by 64, not by 128
+  if (g_wgrad_cfg % 10 == 1) p.bn = 64;
+  if (g_wgrad_cfg % 10 == 2) p.bn = 128;
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
   const int nchunks = cdiv(P, FBK);
   long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
@@ -906,8 +1087,10 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
   if (ns > maxsplit) ns = maxsplit;
   if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;
+  if (ns >= 8) ns = (ns + 7) / 8 * 8;                  // multiples of 8: one split per XCD lane (see kernels)
   p.chunks_per_split = (int)((nchunks + ns - 1) / ns);
   p.nsplit = cdiv(nchunks, p.chunks_per_split);
+  if (p.nsplit >= 8 && p.nsplit % 8 != 0) p.nsplit = (p.nsplit + 7) / 8 * 8;   // empty tail splits write zeros
   return p;
 }
 
@@ -945,9 +1128,15 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   float* partial = static_cast<float*>(workspace);
   float* bias_partial = partial + (size_t)p.nsplit * cout * g.Ktot;
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
-#define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                          \
-  hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
-                     db ? bias_partial : nullptr, xrow, xchan, g)
+#define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
+  do {                                                                                                            \
+    if (!xrow && !xchan && g_wgrad_cfg < 10)                                                                      \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy,     \
+                         partial, db ? bias_partial : nullptr, g);                                               \
+    else                                                                                                          \
+      hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
+                         db ? bias_partial : nullptr, xrow, xchan, g);                                           \
+  } while (0)
   if (p.bm == 128 && p.bn == 128)
     SRHIP_LW(128, 128, 2, 2);
   else if (p.bm == 128)
@@ -960,7 +1149,7 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   int rc = check_launch("fast_wgrad");
   if (rc) return rc;
   const long total = (long)cout * g.Ktot + (db ? cout : 0);
-  hipLaunchKernelGGL(fast_wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, partial, bias_partial, dw,
+  hipLaunchKernelGGL(fast_wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, bias_partial, dw,
                      db, p.nsplit, cout, cin, kh * kw, g.Ktot);
   return check_launch("fast_wgrad_reduce");
 }
