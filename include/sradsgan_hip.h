@@ -89,6 +89,12 @@ int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_b
 /* ---- elementwise / permutation pieces of the same call sites --------------------------------- */
 /* dx = dy * (y > 0 ? 1 : slope): backward of the in-place LeakyReLU (:242,:479) from its OUTPUT  */
 int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream);
+/* nn.MaxPool2d(2,2) of vgg19.features[4] / [9] (sradsgan.py:92-95) on NHWC, even H and W, C % 4 == 0.
+ * bwd recomputes the argmax from x (first maximum in window scan order, like ATen); relu_input != 0
+ * also applies the backward of the ReLU that produced x (dx = 0 where the window maximum is 0).   */
+int srhip_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+int srhip_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int n, int h, int w, int c, int relu_input,
+                         void* stream);
 /* nn.PixelShuffle(r) (:382,:385) on NHWC, fused with the LeakyReLU(slope) that follows it (:383):
  * out[n,h*r+i,w*r+j,c] = act(in[n,h,w,c*r*r+i*r+j]);  backward = inverse permutation * mask(out) */
 int srhip_pixel_shuffle_fwd(const float* in, float* out, int n, int h, int w, int cout, int r,
@@ -113,6 +119,12 @@ size_t srhip_attn_tail_bwd_workspace(int n, int h, int w);
 int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
                                 const int* argc, const float* w7, float* du, float* ds, float* dw7, void* workspace,
                                 size_t workspace_bytes, int n, int h, int w, int c, void* stream);
+/* backward, channel half: ds -> sigmoid -> shared MLP (sradsgan.py:110-112,124-126): davg/dmax [N][64],
+ * dfc1 [hidden][64], dfc2 [64][hidden].                                                             */
+size_t srhip_attn_tail_mlp_workspace(int n, int hidden);
+int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, const float* s, const float* fc1,
+                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, void* workspace,
+                            size_t workspace_bytes, int n, int c, int hidden, void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

@@ -25,12 +25,16 @@ SIGNATURES = {
     'srhip_colsum_workspace': (_sz, [_l, _i]),
     'srhip_colsum': (_i, [_vp, _vp, _vp, _sz, _l, _i, _i, _vp]),
     'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
+    'srhip_maxpool2x2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_attn_tail_workspace': (_sz, [_i]),
     'srhip_attn_tail_fwd': (_i, [_vp] * 12 + [_sz] + [_i] * 5 + [_vp]),
     'srhip_attn_tail_bwd_workspace': (_sz, [_i] * 3),
     'srhip_attn_tail_bwd_spatial': (_i, [_vp] * 11 + [_sz] + [_i] * 4 + [_vp]),
+    'srhip_attn_tail_mlp_workspace': (_sz, [_i, _i]),
+    'srhip_attn_tail_bwd_mlp': (_i, [_vp] * 11 + [_sz] + [_i] * 3 + [_vp]),
     'srhip_attn_tail_bwd_channel': (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     'srhip_bn_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_fwd': (_i, [_vp] * 9 + [_sz, _l, _i, _f, _f, _f, _i, _vp]),

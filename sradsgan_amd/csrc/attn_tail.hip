@@ -346,6 +346,62 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
   *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = d;
 }
 
+// ---- B4b: backward of s = sigmoid(W2 relu(W1 avg) + W2 relu(W1 max)) for one image per block ------- //
+// ds [B][64] -> davg, dmax [B][64] and per-image partials of dW1 [H][64], dW2 [64][H] (summed by the
+// reduce kernel below).  64 threads = 64 channels; H <= 16.
+__global__ void clam_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ avg,
+                                    const float* __restrict__ mx, const float* __restrict__ s,
+                                    const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                    float* __restrict__ davg, float* __restrict__ dmax, float* __restrict__ pw1,
+                                    float* __restrict__ pw2, int hidden) {
+  __shared__ float sa[TC], sm[TC], sdl[TC], pa[16], pm[16], dpa[16], dpm[16];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float sv = s[b * TC + c];
+  const float dl = ds[b * TC + c] * sv * (1.f - sv);
+  const float a_ = avg[b * TC + c], m_ = mx[b * TC + c];
+  sa[c] = a_;
+  sm[c] = m_;
+  sdl[c] = dl;
+  __syncthreads();
+  if (c < hidden) {
+    float x0 = 0.f, x1 = 0.f, dh = 0.f;
+    for (int k = 0; k < TC; ++k) {
+      const float w = fc1[c * TC + k];
+      x0 += w * sa[k];
+      x1 += w * sm[k];
+      dh += fc2[k * hidden + c] * sdl[k];
+    }
+    pa[c] = fmaxf(x0, 0.f);
+    pm[c] = fmaxf(x1, 0.f);
+    dpa[c] = x0 > 0.f ? dh : 0.f;
+    dpm[c] = x1 > 0.f ? dh : 0.f;
+  }
+  __syncthreads();
+  float ga = 0.f, gm = 0.f;
+  for (int j = 0; j < hidden; ++j) {
+    const float w = fc1[j * TC + c];
+    ga += w * dpa[j];
+    gm += w * dpm[j];
+    pw1[((size_t)b * hidden + j) * TC + c] = dpa[j] * a_ + dpm[j] * m_;          // dW1[j][c]
+    pw2[((size_t)b * TC + c) * hidden + j] = dl * (pa[j] + pm[j]);               // dW2[c][j]
+  }
+  davg[b * TC + c] = ga;
+  dmax[b * TC + c] = gm;
+}
+__global__ void clam_mlp_bwd_reduce_kernel(const float* __restrict__ pw1, const float* __restrict__ pw2,
+                                           float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = hidden * TC;
+  if (i >= 2 * per) return;
+  const float* src = i < per ? pw1 + i : pw2 + (i - per);
+  float acc = 0.f;
+  for (int b = 0; b < n; ++b) acc += src[(size_t)b * per];
+  if (i < per)
+    dfc1[i] = acc;
+  else
+    dfc2[i - per] = acc;
+}
+
 constexpr int TAIL_BLK = 16;     // blocks per image in tail_bwd_main
 
 }  // namespace srhip
@@ -412,6 +468,22 @@ int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax,
   const long npix = (long)n * hw;
   hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, as_stream(stream), du, davg, dmax, argmax_hw, hw, npix);
   return check_launch("attn_tail_bwd_channel");
+}
+
+size_t srhip_attn_tail_mlp_workspace(int n, int hidden) { return (size_t)n * 2 * hidden * TC * sizeof(float); }
+
+int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, const float* s, const float* fc1,
+                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, void* workspace,
+                            size_t workspace_bytes, int n, int c, int hidden, void* stream) {
+  SRHIP_REQUIRE(ds && avg && mx && s && fc1 && fc2 && davg && dmax && dfc1 && dfc2, "attn_tail_bwd_mlp: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0, "attn_tail_bwd_mlp: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_mlp_workspace(n, hidden), "attn_tail_bwd_mlp: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* pw1 = static_cast<float*>(workspace);
+  float* pw2 = pw1 + (size_t)n * hidden * TC;
+  hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, ds, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden);
+  hipLaunchKernelGGL(clam_mlp_bwd_reduce_kernel, dim3(cdiv(2 * hidden * TC, 256)), dim3(256), 0, st, pw1, pw2, dfc1, dfc2, n, hidden);
+  return check_launch("attn_tail_bwd_mlp");
 }
 
 }  // extern "C"

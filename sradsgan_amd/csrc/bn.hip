@@ -2,7 +2,7 @@
 // (reference sradsgan.py:478-479; nn.BatchNorm2d: biased variance for normalisation, unbiased for
 // running_var, momentum 0.1, eps 1e-5).  HBM-bound: forward = 2 reads + 1 write of the tensor,
 // backward = 5 reads + 1 write (dy, x, y twice; x-hat is recomputed, never stored).
-// Statistics are reduced in two deterministic stages (<= 1024 row slabs, then per-column); sums are
+// Statistics are reduced in two deterministic stages (<= 256 row slabs, then per-column); sums are
 // taken about a per-channel shift (the first row) so E[d^2] - E[d]^2 does not cancel.
 #include "common.h"
 
@@ -74,10 +74,10 @@ __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* 
                                 float* __restrict__ running_var, int nblk, int c, long rows, float eps,
                                 float momentum) {
   __shared__ float r0[256], r1[256];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;      // 16 columns x 16 slab lanes
   float a = 0.f, b = 0.f;
   if (col < c)
-    for (int k = sub; k < nblk; k += 4) {
+    for (int k = sub; k < nblk; k += 16) {
       a += partial[(size_t)k * 2 * c + col];
       b += partial[(size_t)k * 2 * c + c + col];
     }
@@ -86,8 +86,11 @@ __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* 
   __syncthreads();
   if (sub == 0 && col < c) {
     const int t = threadIdx.x;
-    const float s1 = (r0[t] + r0[t + 64]) + (r0[t + 128] + r0[t + 192]);
-    const float s2 = (r1[t] + r1[t + 64]) + (r1[t + 128] + r1[t + 192]);
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      s1 += r0[t + 16 * k];
+      s2 += r1[t + 16 * k];
+    }
     const float n = (float)rows;
     const float md = s1 / n;
     float var = s2 / n - md * md;
@@ -107,10 +110,10 @@ __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* 
 __global__ void bn_bwd_stage2(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
                               int nblk, int c) {
   __shared__ float r0[256], r1[256];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;
   float a = 0.f, b = 0.f;
   if (col < c)
-    for (int k = sub; k < nblk; k += 4) {
+    for (int k = sub; k < nblk; k += 16) {
       a += partial[(size_t)k * 2 * c + col];
       b += partial[(size_t)k * 2 * c + c + col];
     }
@@ -119,8 +122,13 @@ __global__ void bn_bwd_stage2(const float* __restrict__ partial, float* __restri
   __syncthreads();
   if (sub == 0 && col < c) {
     const int t = threadIdx.x;
-    dbeta[col] = (r0[t] + r0[t + 64]) + (r0[t + 128] + r0[t + 192]);
-    dgamma[col] = (r1[t] + r1[t + 64]) + (r1[t + 128] + r1[t + 192]);
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < 16; ++k) {
+      s1 += r0[t + 16 * k];
+      s2 += r1[t + 16 * k];
+    }
+    dbeta[col] = s1;
+    dgamma[col] = s2;
   }
 }
 
@@ -188,7 +196,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 
 static long bn_nblk(long rows) {
   long nblk = (rows + 63) / 64;
-  return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);
+  return nblk > 256 ? 256 : (nblk < 1 ? 1 : nblk);
 }
 
 }  // namespace srhip
@@ -212,7 +220,7 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3((int)nblk), dim3(256), 0, st, nullptr, x, nullptr, nullptr, nullptr, part,
                      rows, c, rpb, 0.f, 0);
-  hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, part, x, save_mean, save_invstd, running_mean,
+  hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, x, save_mean, save_invstd, running_mean,
                      running_var, (int)nblk, c, rows, eps, momentum);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
@@ -234,7 +242,7 @@ int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const fl
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3((int)nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, part, rows,
                      c, rpb, slope, apply_act);
-  hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, part, dgamma, dbeta, (int)nblk, c);
+  hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, dgamma, dbeta, (int)nblk, c);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;

@@ -91,6 +91,73 @@ __global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dout, const f
   d[3 * r * r] = g.w;
 }
 
+// nn.MaxPool2d(2, 2) on NHWC (vgg19.features[4], [9]); one thread per 4 channels of one output pixel.
+// Ties keep the first element in window scan order (0,0),(0,1),(1,0),(1,1), like ATen.
+__global__ void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c) {
+  const int ho = h / 2, wo = w / 2, c4 = c / 4;
+  const long total = (long)n * ho * wo * c4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % c4);
+  long pix = idx / c4;
+  const int ow = (int)(pix % wo);
+  pix /= wo;
+  const int oh = (int)(pix % ho);
+  const int b = (int)(pix / ho);
+  const float* p = x + (((size_t)b * h + oh * 2) * w + ow * 2) * c + q * 4;
+  const float4 v00 = *reinterpret_cast<const float4*>(p), v01 = *reinterpret_cast<const float4*>(p + c);
+  const float4 v10 = *reinterpret_cast<const float4*>(p + (size_t)w * c), v11 = *reinterpret_cast<const float4*>(p + (size_t)w * c + c);
+  float4 o;
+  o.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+  o.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+  o.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+  o.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+  reinterpret_cast<float4*>(y)[idx] = o;
+}
+
+// backward of MaxPool2d(2,2) fused with the backward of the ReLU that produced its input x (= relu
+// output, so x >= 0): dx = dy at the first maximum of each window if that maximum is > 0, else 0.
+__device__ inline void pool_bwd1(float a, float b, float c, float d, float g, int relu, float& oa, float& ob,
+                                 float& oc, float& od) {
+  int am = 0;
+  float m = a;
+  if (b > m) { m = b; am = 1; }
+  if (c > m) { m = c; am = 2; }
+  if (d > m) { m = d; am = 3; }
+  const float gg = (!relu || m > 0.f) ? g : 0.f;
+  oa = am == 0 ? gg : 0.f;
+  ob = am == 1 ? gg : 0.f;
+  oc = am == 2 ? gg : 0.f;
+  od = am == 3 ? gg : 0.f;
+}
+__global__ void maxpool2x2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                      int n, int h, int w, int c, int relu) {
+  const int ho = h / 2, wo = w / 2, c4 = c / 4;
+  const long total = (long)n * ho * wo * c4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % c4);
+  long pix = idx / c4;
+  const int ow = (int)(pix % wo);
+  pix /= wo;
+  const int oh = (int)(pix % ho);
+  const int b = (int)(pix / ho);
+  const size_t o00 = (((size_t)b * h + oh * 2) * w + ow * 2) * c + q * 4;
+  const size_t o01 = o00 + c, o10 = o00 + (size_t)w * c, o11 = o10 + c;
+  const float4 v00 = *reinterpret_cast<const float4*>(x + o00), v01 = *reinterpret_cast<const float4*>(x + o01);
+  const float4 v10 = *reinterpret_cast<const float4*>(x + o10), v11 = *reinterpret_cast<const float4*>(x + o11);
+  const float4 g = reinterpret_cast<const float4*>(dy)[idx];
+  float4 a, bb, cc, d;
+  pool_bwd1(v00.x, v01.x, v10.x, v11.x, g.x, relu, a.x, bb.x, cc.x, d.x);
+  pool_bwd1(v00.y, v01.y, v10.y, v11.y, g.y, relu, a.y, bb.y, cc.y, d.y);
+  pool_bwd1(v00.z, v01.z, v10.z, v11.z, g.z, relu, a.z, bb.z, cc.z, d.z);
+  pool_bwd1(v00.w, v01.w, v10.w, v11.w, g.w, relu, a.w, bb.w, cc.w, d.w);
+  *reinterpret_cast<float4*>(dx + o00) = a;
+  *reinterpret_cast<float4*>(dx + o01) = bb;
+  *reinterpret_cast<float4*>(dx + o10) = cc;
+  *reinterpret_cast<float4*>(dx + o11) = d;
+}
+
 // column sums of a [rows][ld] matrix, first C columns (bias gradient on the generic conv path).
 // stage 1: <= 1024 blocks, each reduces a contiguous slab of rows with 16-byte loads (T = float4)
 // or scalar loads (T = float); stage 2: 4 row-lanes per column over the block partials.
@@ -125,19 +192,22 @@ __global__ void colsum_stage1(const float* __restrict__ dy, float* __restrict__ 
 }
 __global__ void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk, int c) {
   __shared__ float red[256];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;       // 16 columns x 16 slab lanes
   float s = 0.f;
   if (col < c)
-    for (int b = sub; b < nblk; b += 4) s += partial[(size_t)b * c + col];
+    for (int b = sub; b < nblk; b += 16) s += partial[(size_t)b * c + col];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (sub == 0 && col < c)
-    out[col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+  if (sub == 0 && col < c) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[threadIdx.x + 16 * k];
+    out[col] = t;
+  }
 }
 
 static long colsum_nblk(long rows) {
   long nblk = (rows + 63) / 64;
-  return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);
+  return nblk > 256 ? 256 : (nblk < 1 ? 1 : nblk);
 }
 size_t colsum_workspace_bytes(long rows, int c) { return (size_t)colsum_nblk(rows) * c * sizeof(float); }
 
@@ -149,7 +219,7 @@ int colsum_launch(const float* dy, float* db, void* workspace, long rows, int c,
     hipLaunchKernelGGL(colsum_stage1<float4>, dim3((int)nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld, rpb);
   else
     hipLaunchKernelGGL(colsum_stage1<float>, dim3((int)nblk), dim3(256), 0, st, dy, (float*)workspace, rows, c, ld, rpb);
-  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(c, 64)), dim3(256), 0, st, (const float*)workspace, db, (int)nblk, c);
+  hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, (const float*)workspace, db, (int)nblk, c);
   return check_launch("colsum");
 }
 
@@ -216,6 +286,24 @@ int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_b
     return SRHIP_ERR_WORKSPACE;
   }
   return colsum_launch(dy, db, workspace, rows, c, ld, as_stream(stream));
+}
+
+int srhip_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+  SRHIP_REQUIRE(x && y && n > 0 && h >= 2 && w >= 2 && c >= 4, "maxpool2x2_fwd: bad argument");
+  SRHIP_REQUIRE(c % 4 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool2x2_fwd: C % 4 == 0 and even H, W only");
+  const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, y, n, h, w, c);
+  return check_launch("maxpool2x2_fwd");
+}
+
+int srhip_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int n, int h, int w, int c, int relu_input,
+                         void* stream) {
+  SRHIP_REQUIRE(dy && x && dx && n > 0 && h >= 2 && w >= 2 && c >= 4, "maxpool2x2_bwd: bad argument");
+  SRHIP_REQUIRE(c % 4 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool2x2_bwd: C % 4 == 0 and even H, W only");
+  const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), dy, x, dx, n, h, w,
+                     c, relu_input);
+  return check_launch("maxpool2x2_bwd");
 }
 
 }  // extern "C"

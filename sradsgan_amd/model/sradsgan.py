@@ -312,6 +312,14 @@ class FeatureExtractor(nn.Module):
     def forward(self, img):
         x = ops.nhwc(img)
         fe = self.feature_extractor
+        frozen = not any(p.requires_grad for p in self.parameters())
+        if frozen and x.is_cuda and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0:
+            # the training step's case: weights are in no optimiser (sradsgan.py:724-725), only d/d(img) is needed
+            wb = []
+            for i, item in enumerate(self._CFG):
+                if isinstance(item, tuple):
+                    wb += [fe[i].weight, fe[i].bias]
+            return ops.vgg_features(x, wb)
         for i, item in enumerate(self._CFG):
             if isinstance(item, tuple):
                 x = fe[i](x, act_slope=0.0)          # conv + ReLU fused

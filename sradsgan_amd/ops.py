@@ -394,13 +394,15 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, has_bias, skip_params=Fals
     _hip.check(lib.srhip_attn_tail_bwd_spatial(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc),
                                                _p(w7.detach().contiguous()), _p(du), _p(ds), _p(dw7), _p(ws),
                                                ws.numel() * 4, n, h, w, c, _stream()), 'attn_tail_bwd_spatial')
-    # channel half: ds -> sigmoid -> shared MLP -> (davg, dmax, dfc1, dfc2); [B,64] tensors, torch autograd
-    with torch.enable_grad():
-        a_, m_ = avg.detach().requires_grad_(True), mx.detach().requires_grad_(True)
-        f1, f2 = fc1_w.detach().requires_grad_(True), fc2_w.detach().requires_grad_(True)
-        s_re = _clam_logits(a_, m_, f1, f2)
-        davg, dmax, dfc1, dfc2 = torch.autograd.grad(s_re, [a_, m_, f1, f2], ds)
-    _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg.contiguous()), _p(dmax.contiguous()), _p(arg), n, h,
+    # channel half: ds -> sigmoid -> shared MLP -> (davg, dmax, dfc1, dfc2), one block per image
+    hid = fc1_w.shape[0]
+    davg, dmax = torch.empty(n, c, **f32), torch.empty(n, c, **f32)
+    dfc1, dfc2 = torch.empty(fc1_w.shape, **f32), torch.empty(fc2_w.shape, **f32)
+    ws2 = torch.empty(lib.srhip_attn_tail_mlp_workspace(n, hid) // 4, **f32)
+    _hip.check(lib.srhip_attn_tail_bwd_mlp(_p(ds), _p(avg), _p(mx), _p(s), _p(fc1_w.detach().contiguous()),
+                                           _p(fc2_w.detach().contiguous()), _p(davg), _p(dmax), _p(dfc1), _p(dfc2),
+                                           _p(ws2), ws2.numel() * 4, n, c, hid, _stream()), 'attn_tail_bwd_mlp')
+    _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg), _p(dmax), _p(arg), n, h,
                                                w, c, _stream()), 'attn_tail_bwd_channel')
     return du, dfc1, dfc2, dw7, dwc, dbc
 
@@ -612,8 +614,78 @@ def batch_norm_act(x, bn, slope=None):
     return y
 
 
+def max_pool2x2_raw(x):
+    _require_gpu(x, 'max_pool2x2')
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h // 2, w // 2, x)
+    _hip.check(_hip.lib().srhip_maxpool2x2_fwd(_p(x), _p(y), n, h, w, c, _stream()), 'maxpool2x2_fwd')
+    return y
+
+
+def max_pool2x2_bwd_raw(dy, x, relu_input):
+    dy, x = nhwc(dy), nhwc(x)
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x, memory_format=CL)
+    _hip.check(_hip.lib().srhip_maxpool2x2_bwd(_p(dy), _p(x), _p(dx), n, h, w, c, int(relu_input), _stream()),
+               'maxpool2x2_bwd')
+    return dx
+
+
+class _MaxPool2x2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return max_pool2x2_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return max_pool2x2_bwd_raw(dy, x, False)
+
+
 def max_pool2x2(x):
+    if x.shape[1] % 4 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+        return _MaxPool2x2.apply(x)
     return torch.nn.functional.max_pool2d(x, 2, 2)
+
+
+class _VggFeatures(Function):
+    """vgg19.features[:12] with frozen weights (sradsgan.py:88-99, 836-838) as ONE autograd node whose
+    backward is the data-gradient chain only: every ReLU backward rides in the epilogue of the dgrad
+    (or in the max-pool backward) that produces its input gradient -- no separate mask passes."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        x = nhwc(x)
+        y1 = conv2d_fwd_raw(x, ws[0], bs[0], 1, 1, 0.0)
+        y2 = conv2d_fwd_raw(y1, ws[1], bs[1], 1, 1, 0.0)
+        p1 = max_pool2x2_raw(y2)
+        y3 = conv2d_fwd_raw(p1, ws[2], bs[2], 1, 1, 0.0)
+        y4 = conv2d_fwd_raw(y3, ws[3], bs[3], 1, 1, 0.0)
+        p2 = max_pool2x2_raw(y4)
+        y5 = conv2d_fwd_raw(p2, ws[4], bs[4], 1, 1, 0.0)
+        ctx.save_for_backward(y1, y2, p1, y3, y4, p2, y5, *ws)
+        ctx.x_shape = tuple(x.shape)
+        return y5
+
+    @staticmethod
+    def backward(ctx, g):
+        y1, y2, p1, y3, y4, p2, y5, w1, w2, w3, w4, w5 = ctx.saved_tensors
+        g = lrelu_bwd_raw(g, y5, 0.0)                                            # ReLU after conv3_1 (54x54, small)
+        g = conv2d_dgrad_raw(g, w5, tuple(p2.shape), 1, 1)
+        g = max_pool2x2_bwd_raw(g, y4, True)                                      # pool2 + ReLU(conv2_2)
+        g = conv2d_dgrad_raw(g, w4, tuple(y3.shape), 1, 1, None, y3, 0.0)         # + ReLU(conv2_1)
+        g = conv2d_dgrad_raw(g, w3, tuple(p1.shape), 1, 1)
+        g = max_pool2x2_bwd_raw(g, y2, True)                                      # pool1 + ReLU(conv1_2)
+        g = conv2d_dgrad_raw(g, w2, tuple(y1.shape), 1, 1, None, y1, 0.0)         # + ReLU(conv1_1)
+        g = conv2d_dgrad_raw(g, w1, ctx.x_shape, 1, 1)
+        return (g,) + (None,) * 10
+
+
+def vgg_features(x, weights_and_biases):
+    return _VggFeatures.apply(x, *weights_and_biases)
 
 
 def l1_mean(a, b):

@@ -197,3 +197,25 @@ def test_adam_kernel_matches_torch():
         step._adam(step.arena_G, 2e-4, 0.05, 1.0)
         for (p, q) in zip(net.parameters(), ref.parameters()):
             assert float((p.detach().cpu() - q.detach()).abs().max()) < 2e-7, it
+
+
+def test_vgg_features_fused_forward_and_input_gradient():
+    """FeatureExtractor (vgg19.features[:12] structure, sradsgan.py:88-99) with frozen weights runs as one
+    fused node (ReLU masks in the dgrad / max-pool epilogues): forward and d/d(img) vs the CPU oracle."""
+    from sradsgan_amd import model as M
+    of = O.FeatureExtractor()
+    O.det_init_(of, prefix='F.')
+    hf = M.FeatureExtractor()
+    hf.load_state_dict(of.state_dict())
+    hf.to(DEV)
+    for p in hf.parameters():
+        p.requires_grad_(False)
+    img = O.det_fill('vgg.img', (2, 3, 24, 32), 0.5, 0.5)
+    xo = img.clone().requires_grad_(True)
+    xh = img.clone().to(DEV).requires_grad_(True)
+    yo, yh = of(xo), hf(xh)
+    dy = O.det_fill('vgg.dy', tuple(yo.shape), 1.0)
+    yo.backward(dy)
+    yh.backward(dy.to(DEV))
+    _close(yh.detach().cpu(), yo.detach(), msg='features')
+    _close(xh.grad.cpu(), xo.grad, msg='d/d(img)')
