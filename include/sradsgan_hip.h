@@ -73,11 +73,14 @@ int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const fl
  *      bias gradient db[co] = sum over pixels of dy.  Deterministic two-pass split-K (no atomics);
  *      `workspace` must hold srhip_conv2d_wgrad_workspace() bytes.  Optional xrowscale [N*H*W] /
  *      xchanscale [N][Cin]: x is read as x * xrowscale[pixel] * xchanscale[n][c] (the un-materialised
- *      input of the attention tail's 1x1 conv, sradsgan.py:262).                                  */
+ *      input of the attention tail's 1x1 conv, sradsgan.py:262).  accumulate != 0 (only where
+ *      srhip_conv2d_wgrad_can_accumulate): dw += ..., db += ... -- lets the caller point dw/db at the
+ *      parameter's .grad slice of the gradient arena instead of paying one add launch per parameter. */
 size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
                                     int pad);
+int srhip_conv2d_wgrad_can_accumulate(int cin, int cout, int kh, int kw);
 int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* db, const float* xrowscale,
-                       const float* xchanscale, void* workspace,
+                       const float* xchanscale, int accumulate, void* workspace,
                        size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw,
                        int stride, int pad, int ldx, int ldy, void* stream);
 
@@ -117,14 +120,14 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
  * (tiny, [N,64]) to davg/dmax and finishes with srhip_attn_tail_bwd_channel (in place on du).      */
 size_t srhip_attn_tail_bwd_workspace(int n, int h, int w);
 int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
-                                const int* argc, const float* w7, float* du, float* ds, float* dw7, void* workspace,
-                                size_t workspace_bytes, int n, int h, int w, int c, void* stream);
+                                const int* argc, const float* w7, float* du, float* ds, float* dw7, int accumulate_dw7,
+                                void* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream);
 /* backward, channel half: ds -> sigmoid -> shared MLP (sradsgan.py:110-112,124-126): davg/dmax [N][64],
  * dfc1 [hidden][64], dfc2 [64][hidden].                                                             */
 size_t srhip_attn_tail_mlp_workspace(int n, int hidden);
 int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, const float* s, const float* fc1,
-                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, void* workspace,
-                            size_t workspace_bytes, int n, int c, int hidden, void* stream);
+                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, int accumulate_dfc,
+                            void* workspace, size_t workspace_bytes, int n, int c, int hidden, void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

@@ -21,7 +21,8 @@ SIGNATURES = {
     'srhip_conv2d_fwd': (_i, [_vp] * 7 + [_i] * 12 + [_f, _i, _vp]),
     'srhip_conv2d_dgrad': (_i, [_vp] * 5 + [_f] + [_i] * 13 + [_vp]),
     'srhip_conv2d_wgrad_workspace': (_sz, [_i] * 9),
-    'srhip_conv2d_wgrad': (_i, [_vp] * 7 + [_sz] + [_i] * 11 + [_vp]),
+    'srhip_conv2d_wgrad_can_accumulate': (_i, [_i] * 4),
+    'srhip_conv2d_wgrad': (_i, [_vp] * 6 + [_i, _vp, _sz] + [_i] * 11 + [_vp]),
     'srhip_colsum_workspace': (_sz, [_l, _i]),
     'srhip_colsum': (_i, [_vp, _vp, _vp, _sz, _l, _i, _i, _vp]),
     'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
@@ -32,9 +33,9 @@ SIGNATURES = {
     'srhip_attn_tail_workspace': (_sz, [_i]),
     'srhip_attn_tail_fwd': (_i, [_vp] * 12 + [_sz] + [_i] * 5 + [_vp]),
     'srhip_attn_tail_bwd_workspace': (_sz, [_i] * 3),
-    'srhip_attn_tail_bwd_spatial': (_i, [_vp] * 11 + [_sz] + [_i] * 4 + [_vp]),
+    'srhip_attn_tail_bwd_spatial': (_i, [_vp] * 10 + [_i, _vp, _sz] + [_i] * 4 + [_vp]),
     'srhip_attn_tail_mlp_workspace': (_sz, [_i, _i]),
-    'srhip_attn_tail_bwd_mlp': (_i, [_vp] * 11 + [_sz] + [_i] * 3 + [_vp]),
+    'srhip_attn_tail_bwd_mlp': (_i, [_vp] * 10 + [_i, _vp, _sz] + [_i] * 3 + [_vp]),
     'srhip_attn_tail_bwd_channel': (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     'srhip_bn_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_fwd': (_i, [_vp] * 9 + [_sz, _l, _i, _f, _f, _f, _i, _vp]),

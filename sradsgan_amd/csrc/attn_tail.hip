@@ -264,12 +264,13 @@ __global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __re
     part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw7, int nblk) {
+__global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw7, int nblk,
+                                               int accumulate) {
   const int t = blockIdx.x;                          // one wave per tap
   float s = 0.f;
   for (int k = threadIdx.x; k < nblk; k += 64) s += part[(size_t)t * nblk + k];
   s = wave_sum(s);
-  if (threadIdx.x == 0) dw7[t] = s;
+  if (threadIdx.x == 0) dw7[t] = accumulate ? dw7[t] + s : s;
 }
 
 // ---- B3: dy = m*dz + dpooled.x/C + [c == argc]*dpooled.y ; du = s*dy ; ds partial = sum_pix dy*u --- //
@@ -389,17 +390,16 @@ __global__ void clam_mlp_bwd_kernel(const float* __restrict__ ds, const float* _
   dmax[b * TC + c] = gm;
 }
 __global__ void clam_mlp_bwd_reduce_kernel(const float* __restrict__ pw1, const float* __restrict__ pw2,
-                                           float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden) {
+                                           float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden,
+                                           int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int per = hidden * TC;
   if (i >= 2 * per) return;
   const float* src = i < per ? pw1 + i : pw2 + (i - per);
   float acc = 0.f;
   for (int b = 0; b < n; ++b) acc += src[(size_t)b * per];
-  if (i < per)
-    dfc1[i] = acc;
-  else
-    dfc2[i - per] = acc;
+  float* o = i < per ? dfc1 + i : dfc2 + (i - per);
+  *o = accumulate ? *o + acc : acc;
 }
 
 constexpr int TAIL_BLK = 16;     // blocks per image in tail_bwd_main
@@ -436,8 +436,8 @@ size_t srhip_attn_tail_bwd_workspace(int n, int h, int w) {
 }
 
 int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
-                                const int* argc, const float* w7, float* du, float* ds, float* dw7, void* workspace,
-                                size_t workspace_bytes, int n, int h, int w, int c, void* stream) {
+                                const int* argc, const float* w7, float* du, float* ds, float* dw7, int accumulate_dw7,
+                                void* workspace, size_t workspace_bytes, int n, int h, int w, int c, void* stream) {
   SRHIP_REQUIRE(dz && u && s && m && pooled && argc && w7 && du && ds && dw7, "attn_tail_bwd_spatial: null tensor");
   SRHIP_REQUIRE(c == TC && n > 0 && h > 0 && w > 0, "attn_tail_bwd_spatial: C must be 64");
   const int hw = h * w;
@@ -453,7 +453,7 @@ int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s,
   hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
   const int w7blk = (int)(cdiv(npix, 256) < W7_BLOCKS ? cdiv(npix, 256) : W7_BLOCKS);
   hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), 0, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, npix);
-  hipLaunchKernelGGL(slam_conv7_wgrad_reduce_kernel, dim3(98), dim3(64), 0, st, w7part, dw7, w7blk);
+  hipLaunchKernelGGL(slam_conv7_wgrad_reduce_kernel, dim3(98), dim3(64), 0, st, w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(tail_bwd_main_kernel, dim3(TAIL_BLK, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw);
   hipLaunchKernelGGL(tail_bwd_ds_kernel, dim3(n), dim3(TC), 0, st, dsp, ds, TAIL_BLK);
   return check_launch("attn_tail_bwd_spatial");
@@ -473,8 +473,8 @@ int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax,
 size_t srhip_attn_tail_mlp_workspace(int n, int hidden) { return (size_t)n * 2 * hidden * TC * sizeof(float); }
 
 int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, const float* s, const float* fc1,
-                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, void* workspace,
-                            size_t workspace_bytes, int n, int c, int hidden, void* stream) {
+                            const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, int accumulate_dfc,
+                            void* workspace, size_t workspace_bytes, int n, int c, int hidden, void* stream) {
   SRHIP_REQUIRE(ds && avg && mx && s && fc1 && fc2 && davg && dmax && dfc1 && dfc2, "attn_tail_bwd_mlp: null tensor");
   SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0, "attn_tail_bwd_mlp: C must be 64, hidden <= 16");
   SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_mlp_workspace(n, hidden), "attn_tail_bwd_mlp: workspace too small");
@@ -482,7 +482,7 @@ int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, 
   float* pw1 = static_cast<float*>(workspace);
   float* pw2 = pw1 + (size_t)n * hidden * TC;
   hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, ds, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden);
-  hipLaunchKernelGGL(clam_mlp_bwd_reduce_kernel, dim3(cdiv(2 * hidden * TC, 256)), dim3(256), 0, st, pw1, pw2, dfc1, dfc2, n, hidden);
+  hipLaunchKernelGGL(clam_mlp_bwd_reduce_kernel, dim3(cdiv(2 * hidden * TC, 256)), dim3(256), 0, st, pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc);
   return check_launch("attn_tail_bwd_mlp");
 }
 

@@ -97,8 +97,10 @@ size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int 
          (rows > 0 ? colsum_workspace_bytes(rows, cout) : 0);
 }
 
+int srhip_conv2d_wgrad_can_accumulate(int cin, int cout, int kh, int kw) { return fast_wgrad_ok(cin, cout, kh, kw) ? 1 : 0; }
+
 int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrowscale,
-                       const float* xchanscale, void* workspace,
+                       const float* xchanscale, int accumulate, void* workspace,
                        size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
                        int pad, int ldx, int ldy, void* stream) {
   SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
@@ -106,9 +108,10 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, co
                 "conv2d_wgrad: bad geometry");
   SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_wgrad: row stride smaller than channel count");
   if (fast_wgrad_ok(cin, cout, kh, kw))
-    return fast_conv2d_wgrad(x, dy, dw, db, xrowscale, xchanscale, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx,
+    return fast_conv2d_wgrad(x, dy, dw, db, xrowscale, xchanscale, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx,
                              ldy, as_stream(stream));
-  SRHIP_REQUIRE(!xrowscale && !xchanscale, "conv2d_wgrad: x scaling needs Cin % 64 == 0 and Cout % 4 == 0");
+  SRHIP_REQUIRE(!xrowscale && !xchanscale && !accumulate,
+                "conv2d_wgrad: x scaling / accumulate need Cin % 16 == 0 and Cout % 4 == 0 (srhip_conv2d_wgrad_can_accumulate)");
   const size_t need = srhip_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
   if (!workspace || workspace_bytes < need) {
     set_error("conv2d_wgrad: workspace %zu bytes < required %zu", workspace_bytes, need);

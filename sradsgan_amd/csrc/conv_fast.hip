@@ -866,7 +866,8 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
 __global__ __launch_bounds__(256) void fast_wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                  const float* __restrict__ bias_partial,
                                                                  float* __restrict__ dw, float* __restrict__ db,
-                                                                 int nsplit, int cout, int cin, int khkw, int ktot) {
+                                                                 int nsplit, int cout, int cin, int khkw, int ktot,
+                                                                 int accumulate) {
   // 64 outputs per block x 4 split lanes; each lane keeps 4 loads in flight, LDS combines the lanes
   __shared__ float red[256];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
@@ -893,9 +894,10 @@ __global__ __launch_bounds__(256) void fast_wgrad_reduce_kernel(const float* __r
     if (e < total) {
       const int co = e / ktot, kcol = e - co * ktot;
       const int tap = kcol / cin, ci = kcol - tap * cin;
-      dw[((size_t)co * cin + ci) * khkw + tap] = v;
+      float* o = dw + ((size_t)co * cin + ci) * khkw + tap;
+      *o = accumulate ? *o + v : v;
     } else if (db != nullptr && e < total + cout) {
-      db[e - total] = v;
+      db[e - total] = accumulate ? db[e - total] + v : v;
     }
   }
 }
@@ -1103,7 +1105,7 @@ size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int k
 }
 
 int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrow, const float* xchan,
-                      void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
+                      int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
                       hipStream_t st) {
   SRHIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
                 "conv2d_wgrad: x/dy must be 16-byte aligned with row strides % 4 == 0");
@@ -1150,7 +1152,7 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   if (rc) return rc;
   const long total = (long)cout * g.Ktot + (db ? cout : 0);
   hipLaunchKernelGGL(fast_wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, bias_partial, dw,
-                     db, p.nsplit, cout, cin, kh * kw, g.Ktot);
+                     db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
   return check_launch("fast_wgrad_reduce");
 }
 

@@ -32,7 +32,7 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
                       int ldx, int ldr, int accumulate, hipStream_t st);
 size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
 int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrow, const float* xchan,
-                      void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
+                      int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
                       hipStream_t st);
 
 // column sums (elementwise.hip), used for the bias gradient on the generic path

@@ -23,6 +23,7 @@ CL = torch.channels_last
 class _State:
     # a plain global, not threading.local: autograd runs Function.backward on its own device thread
     skip_param_grads = False
+    direct_grads = False
 
 
 _state = _State()
@@ -43,6 +44,31 @@ def no_param_grads():
         yield
     finally:
         _state.skip_param_grads = prev
+
+
+@contextlib.contextmanager
+def direct_param_grads():
+    """Inside this context the fused backward kernels ACCUMULATE parameter gradients straight into the
+    parameters' existing .grad buffers (the gradient arena of dp.ParamArena) and hand autograd None for
+    them: one wgrad launch per conv instead of wgrad + one `grad += new` launch per parameter
+    (~600 tiny launches per step).  Only valid when every such parameter already owns a dense .grad
+    and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
+    prev = _state.direct_grads
+    _state.direct_grads = True
+    try:
+        yield
+    finally:
+        _state.direct_grads = prev
+
+
+def _grad_slot(p):
+    """The buffer to accumulate into, or None when direct accumulation is off / impossible for p."""
+    if not _state.direct_grads or p is None or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.device != p.device:
+        return None
+    return g
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -159,8 +185,9 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, s
     return dx
 
 
-def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=None, xchanscale=None):
-    """(dw [OIHW], db [Cout] or None): the bias gradient comes out of the same kernel pass."""
+def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=None, xchanscale=None, out=None):
+    """(dw [OIHW], db [Cout] or None): the bias gradient comes out of the same kernel pass.
+    out=(dw_buf, db_buf or None): accumulate into these buffers instead (dw_buf += dw, db_buf += db)."""
     _require_gpu(x, 'conv2d_wgrad')
     x, dy = nhwc(x), nhwc(dy)
     n, cin, h, wd = x.shape
@@ -168,11 +195,30 @@ def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=Non
     lib = _hip.lib()
     nbytes = lib.srhip_conv2d_wgrad_workspace(n, h, wd, cin, cout, kh, kw, stride, pad)
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
-    db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
-    _hip.check(lib.srhip_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(xrowscale), _p(xchanscale), _p(ws), ws.numel() * 4, n, h, wd, cin, cout, kh,
-                                      kw, stride, pad, cin, cout, _stream()), 'conv2d_wgrad')
+    if out is None:
+        dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+        db = torch.empty(cout, device=x.device, dtype=torch.float32) if with_bias else None
+        acc = 0
+    else:
+        dw, db = out
+        acc = 1
+    _hip.check(lib.srhip_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(xrowscale), _p(xchanscale), acc, _p(ws),
+                                      ws.numel() * 4, n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout, _stream()),
+               'conv2d_wgrad')
     return dw, db
+
+
+def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscale=None):
+    """(dw, db) to return to autograd for parameters (w, b).  In direct_param_grads() mode the kernel
+    accumulates into w.grad / b.grad and this returns (None, None)."""
+    cout, cin, kh, kw = w.shape
+    gw = _grad_slot(w)
+    gb = _grad_slot(b) if (want_b and b is not None) else None
+    if gw is not None and (not want_b or gb is not None) and \
+            _hip.lib().srhip_conv2d_wgrad_can_accumulate(cin, cout, kh, kw):
+        conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+        return None, None
+    return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
 
 
 def colsum_raw(dy):
@@ -238,18 +284,20 @@ class _ConvFwd(Function):
         y = conv2d_fwd_raw(x, w, b, stride, pad, slope, residual)
         ctx.stride, ctx.pad, ctx.slope = stride, pad, slope
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
-        ctx.save_for_backward(x, w, y if slope is not None else None)
+        ctx.save_for_backward(x, w, y if slope is not None else None, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, b = ctx.saved_tensors
         g = dy if ctx.slope is None else _LReluBwd.apply(dy, y, ctx.slope)
         skip = _skip_param_grads()
         dx = _ConvDgrad.apply(g, w, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not skip
-        if ctx.needs_input_grad[1] and not skip:
+        if ctx.needs_input_grad[1] and not skip and _state.direct_grads and not torch.is_grad_enabled():
+            dw, db = wgrad_for_params(w, b, x, g, ctx.stride, ctx.pad, want_b)
+        elif ctx.needs_input_grad[1] and not skip:
             dw, db = _ConvWgrad.apply(x, g, tuple(w.shape), ctx.stride, ctx.pad, want_b)
         elif want_b:
             db = _ColSum.apply(g)
@@ -378,7 +426,7 @@ def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
     return out, (avg, mx, arg, s, pooled, argc, m)
 
 
-def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, has_bias, skip_params=False):
+def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=False):
     """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc)."""
     avg, mx, arg, s, pooled, argc, m = saved
     n, c, h, w = u.shape
@@ -387,21 +435,32 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, has_bias, skip_params=Fals
     dz = conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)                              # gradient at z = m*s*u
     dwc = dbc = None
     if not skip_params:
-        dwc, dbc = conv2d_wgrad_raw(u, g, tuple(wc.shape), 1, 0, has_bias, m, s)    # x operand = z, rebuilt on the fly
+        dwc, dbc = wgrad_for_params(wc, bc, u, g, 1, 0, has_bias, m, s)             # x operand = z, rebuilt on the fly
     du = torch.empty_like(u, memory_format=CL)
-    ds, dw7 = torch.empty(n, c, **f32), torch.empty(w7.shape, **f32)
+    ds = torch.empty(n, c, **f32)
+    g7 = None if skip_params else _grad_slot(w7)
+    dw7 = g7 if g7 is not None else torch.empty(w7.shape, **f32)
     ws = torch.empty(lib.srhip_attn_tail_bwd_workspace(n, h, w) // 4, **f32)
     _hip.check(lib.srhip_attn_tail_bwd_spatial(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc),
-                                               _p(w7.detach().contiguous()), _p(du), _p(ds), _p(dw7), _p(ws),
-                                               ws.numel() * 4, n, h, w, c, _stream()), 'attn_tail_bwd_spatial')
+                                               _p(w7.detach().contiguous()), _p(du), _p(ds), _p(dw7),
+                                               int(g7 is not None), _p(ws), ws.numel() * 4, n, h, w, c, _stream()),
+               'attn_tail_bwd_spatial')
+    if g7 is not None:
+        dw7 = None
     # channel half: ds -> sigmoid -> shared MLP -> (davg, dmax, dfc1, dfc2), one block per image
     hid = fc1_w.shape[0]
     davg, dmax = torch.empty(n, c, **f32), torch.empty(n, c, **f32)
-    dfc1, dfc2 = torch.empty(fc1_w.shape, **f32), torch.empty(fc2_w.shape, **f32)
+    g1, g2 = (None, None) if skip_params else (_grad_slot(fc1_w), _grad_slot(fc2_w))
+    direct = g1 is not None and g2 is not None
+    dfc1 = g1 if direct else torch.empty(fc1_w.shape, **f32)
+    dfc2 = g2 if direct else torch.empty(fc2_w.shape, **f32)
     ws2 = torch.empty(lib.srhip_attn_tail_mlp_workspace(n, hid) // 4, **f32)
     _hip.check(lib.srhip_attn_tail_bwd_mlp(_p(ds), _p(avg), _p(mx), _p(s), _p(fc1_w.detach().contiguous()),
                                            _p(fc2_w.detach().contiguous()), _p(davg), _p(dmax), _p(dfc1), _p(dfc2),
-                                           _p(ws2), ws2.numel() * 4, n, c, hid, _stream()), 'attn_tail_bwd_mlp')
+                                           int(direct), _p(ws2), ws2.numel() * 4, n, c, hid, _stream()),
+               'attn_tail_bwd_mlp')
+    if direct:
+        dfc1 = dfc2 = None
     _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg), _p(dmax), _p(arg), n, h,
                                                w, c, _stream()), 'attn_tail_bwd_channel')
     return du, dfc1, dfc2, dw7, dwc, dbc
@@ -413,15 +472,15 @@ class _AttentionTail(Function):
         _require_gpu(u, 'attention_tail')
         u, skip = nhwc(u), nhwc(skip)
         out, saved = _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc)
-        ctx.save_for_backward(u, fc1_w, fc2_w, w7, wc, *saved)
+        ctx.save_for_backward(u, fc1_w, fc2_w, w7, wc, bc, *saved)
         ctx.has_bias = bc is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        u, fc1_w, fc2_w, w7, wc, *saved = ctx.saved_tensors
+        u, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
         g = nhwc(g)
-        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, ctx.has_bias,
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_bias,
                                                        _skip_param_grads())
         return du, g, dfc1, dfc2, dw7, dwc, dbc
 
@@ -440,23 +499,23 @@ class _RabBlock(Function):
         t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
         u = conv2d_fwd_raw(t, w2, b2, 1, 1)
         out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc)
-        ctx.save_for_backward(x, t, u, w1, w2, fc1_w, fc2_w, w7, wc, *saved)
+        ctx.save_for_backward(x, t, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved)
         ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, t, u, w1, w2, fc1_w, fc2_w, w7, wc, *saved = ctx.saved_tensors
+        x, t, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
         g = nhwc(g)
         skip = _skip_param_grads()
-        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, saved, ctx.has_b[2], skip)
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_b[2], skip)
         dt = conv2d_dgrad_raw(du, w2, tuple(t.shape), 1, 1, None, t, 0.2)          # * LeakyReLU'(t)
         dw2 = db2 = dw1 = db1 = None
         if not skip:
-            dw2, db2 = conv2d_wgrad_raw(t, du, tuple(w2.shape), 1, 1, ctx.has_b[1])
+            dw2, db2 = wgrad_for_params(w2, b2, t, du, 1, 1, ctx.has_b[1])
         dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g) if ctx.needs_input_grad[0] else None   # + skip gradient
         if not skip:
-            dw1, db1 = conv2d_wgrad_raw(x, dt, tuple(w1.shape), 1, 1, ctx.has_b[0])
+            dw1, db1 = wgrad_for_params(w1, b1, x, dt, 1, 1, ctx.has_b[0])
         return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
 
 

@@ -128,7 +128,8 @@ class TrainStep:
     def __call__(self, imgs_lr, imgs_hr, alpha):
         self._calls += 1
         if not self.use_graph:
-            out = self._compute(imgs_lr, imgs_hr, alpha)
+            with ops.direct_param_grads():           # wgrad kernels accumulate straight into the gradient arenas
+                out = self._compute(imgs_lr, imgs_hr, alpha)
             self._update()
             return out
         if self._calls == 1:
