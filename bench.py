@@ -97,9 +97,16 @@ def time_dominant_kernel(device, batch):
     ms = s.elapsed_time(e) / iters
     flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9
     achieved = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'igemm_fprop 3x3 64->256 @54x54 (RAB conv1)', 'achieved': round(achieved, 2),
-            'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            'traffic': None, 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4), 'dtype_peak': 'f32 MFMA dense'}
+    traffic = None                      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape)
+    if batch == PER_GPU_BATCH:
+        try:
+            traffic = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            traffic = None
+    return {'bound': 'mfma', 'kernel': 'fast_conv_dma_kernel<128,128,3>: 3x3 64->256 @54x54 +bias +LeakyReLU (RAB conv1)',
+            'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'flops_per_launch': flops,
+            'avg_launch_ms': round(ms, 4), 'dtype_peak': 'f32 MFMA dense'}
 
 
 def usable_cores():

@@ -150,11 +150,14 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
       const unsigned off = bval[j] ? (unsigned)(bbase[j] + wk) * 4u : F_OOB;
       rb[j] = bufload4(rw, off);
     }
-    if (++cc == CC) {
-      cc = 0;
-      if (++tw == g.TW) {
-        tw = 0;
-        ++th;
+    // taps innermost: the 9 taps of one 16-channel chunk re-read the same 64-byte segments of ~3 image
+    // rows back to back (L1/L2 hits); with taps outermost a 256-channel input was re-fetched 9x from
+    // beyond L2 (FETCH_SIZE 788 MB vs 96 MB algorithmic, profiles/r01_conv_pmc_summary.txt)
+    if (++tw == g.TW) {
+      tw = 0;
+      if (++th == g.TH) {
+        th = 0;
+        ++cc;
       }
     }
   };
@@ -376,11 +379,14 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
       const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
       lds_dma16(p, b_dst + so + j * 1024);
     }
-    if (++cc == CC) {
-      cc = 0;
-      if (++tw == g.TW) {
-        tw = 0;
-        ++th;
+    // taps innermost: the 9 taps of one 16-channel chunk re-read the same 64-byte segments of ~3 image
+    // rows back to back (L1/L2 hits); with taps outermost a 256-channel input was re-fetched 9x from
+    // beyond L2 (FETCH_SIZE 788 MB vs 96 MB algorithmic, profiles/r01_conv_pmc_summary.txt)
+    if (++tw == g.TW) {
+      tw = 0;
+      if (++th == g.TH) {
+        th = 0;
+        ++cc;
       }
     }
   };
