@@ -460,38 +460,71 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
     }
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: accumulators -> LDS (per-wave region of the now idle ring) -> row-contiguous float4s:
+  // 16-byte loads of bias / mask / residual and 16-byte stores (4 rows x 256 B per wave instruction)
+  // instead of 64 scalar stores per lane.  C/D map of the 32x32 MFMA: col = lane&31,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const int flags = EPI >= 0 ? EPI : g.flags;
+  __syncthreads();                                   // every wave is done reading the ring
+  float* wl = reinterpret_cast<float*>(lds) + wave * (32 * WTN);
+  constexpr int QPRW = WTN / 4;                      // float4 per tile row
+  constexpr int NRD = 32 * QPRW / 64;                // float4 reads per lane per 32-row half
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      if (m >= g.M) continue;
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + u * 32 + l31] = acc[t][u][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private region: no block barrier needed
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      const int idx = i * 64 + lane;
+      const int row = idx / QPRW, cq = idx - row * QPRW;
+      float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+      const int m = m0 + wm * WTM + t * 32 + row;
+      const int n = n0 + wn * WTN + cq * 4;
+      if (m >= g.M || n >= g.K) continue;
       size_t dpix = (size_t)m;
       if (!g.dst_identity) {
-        const int n = m / OHOW;
-        const int rem = m - n * OHOW;
+        const int nimg = m / OHOW;
+        const int rem = m - nimg * OHOW;
         const int oh = rem / g.OW;
         const int ow = rem - oh * g.OW;
-        dpix = ((size_t)n * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
+        dpix = ((size_t)nimg * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
       }
-      const float rsc = (flags & SRHIP_EPI_ROWSCALE) ? rowscale[dpix] : 1.f;
-#pragma unroll
-      for (int u = 0; u < TN; ++u) {
-        const int n = n0 + wn * WTN + u * 32 + l31;
-        if (n >= g.K) continue;
-        float v = acc[t][u][r];
-        if (flags & SRHIP_EPI_ROWSCALE) v *= rsc;
-        if (flags & SRHIP_EPI_BIAS) v += bias[n];
-        if (flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
-        if (flags & SRHIP_EPI_ACTMASK) v = actmask[dpix * g.ldd + n] > 0.f ? v : v * g.slope;
-        if (flags & SRHIP_EPI_RESIDUAL) v += residual[dpix * g.ldr + n];
-        float* o = dst + dpix * g.ldd + n;
-        if (g.accumulate) v += *o;
-        *o = v;
+      if (flags & SRHIP_EPI_ROWSCALE) {
+        const float rsc = rowscale[dpix];
+        v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
       }
+      if (flags & SRHIP_EPI_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (flags & SRHIP_EPI_LRELU) {
+        v.x = v.x > 0.f ? v.x : v.x * g.slope;
+        v.y = v.y > 0.f ? v.y : v.y * g.slope;
+        v.z = v.z > 0.f ? v.z : v.z * g.slope;
+        v.w = v.w > 0.f ? v.w : v.w * g.slope;
+      }
+      if (flags & SRHIP_EPI_ACTMASK) {
+        const float4 a4 = *reinterpret_cast<const float4*>(actmask + dpix * g.ldd + n);
+        v.x = a4.x > 0.f ? v.x : v.x * g.slope;
+        v.y = a4.y > 0.f ? v.y : v.y * g.slope;
+        v.z = a4.z > 0.f ? v.z : v.z * g.slope;
+        v.w = a4.w > 0.f ? v.w : v.w * g.slope;
+      }
+      if (flags & SRHIP_EPI_RESIDUAL) {
+        const float4 r4 = *reinterpret_cast<const float4*>(residual + dpix * g.ldr + n);
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
+      float4* o = reinterpret_cast<float4*>(dst + dpix * g.ldd + n);
+      if (g.accumulate) {
+        const float4 p4 = *o;
+        v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+      }
+      *o = v;
     }
+    if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the region is rewritten
   }
 }
 
@@ -713,16 +746,16 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict
 // ---- wgrad, LDS-DMA variant: same ring / counted-vmcnt structure as fast_conv_dma_kernel.  Both
 // operands are pixel-major, so a stage is simply [16 pixels][BM] + [16 pixels][BN] floats, written
 // lane-linear by the DMA and read back as conflict-free ds_read_b32 (consecutive dwords) -- no swizzle.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WBK>
 __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partial,
                                                               float* __restrict__ bias_partial, WgradGeom g) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AI = BM / 64, BI = BN / 64;              // DMA instructions per wave per chunk
+  constexpr int AI = BM * WBK / 1024, BI = BN * WBK / 1024;   // DMA instructions per wave per chunk
   constexpr int ALR = BM / 4, BLR = BN / 4;              // lanes per pixel row
   constexpr int ARPI = 64 / ALR, BRPI = 64 / BLR;        // pixel rows per DMA instruction
-  constexpr int STAGE_B = (BM + BN) * FBK * 4;
+  constexpr int STAGE_B = (BM + BN) * WBK * 4;
   __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE_B];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -749,7 +782,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
   const int c_begin = split * g.chunks_per_split;
-  const int nchunks_total = (g.P + FBK - 1) / FBK;
+  const int nchunks_total = (g.P + WBK - 1) / WBK;
   const int c_end = min(c_begin + g.chunks_per_split, nchunks_total);
   const int nk = c_end - c_begin;
 
@@ -769,21 +802,21 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
   const int HoWo = g.Ho * g.Wo;
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
-    const int p = c_begin * FBK + (wave * BI + j) * BRPI + lane / BLR;
+    const int p = c_begin * WBK + (wave * BI + j) * BRPI + lane / BLR;
     bn[j] = p / HoWo;
     const int rem = p - bn[j] * HoWo;
     bho[j] = rem / g.Wo;
     bwo[j] = rem - bho[j] * g.Wo;
   }
   const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * AI * 1024);
-  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + BM * FBK * 4 + wave * BI * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + BM * WBK * 4 + wave * BI * 1024);
 
   int kc_issue = c_begin;
   auto issue = [&](int stage) {
     const unsigned so = stage * STAGE_B;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int p = kc_issue * FBK + arow[i];
+      const int p = kc_issue * WBK + arow[i];
       const float* ptr = (p < g.P && a_colok) ? dy + ((long)p * g.ldy + m0 + acol * 4) : g_zero16;
       lds_dma16(ptr, a_dst + so + i * 1024);
     }
@@ -793,7 +826,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
       const bool ok = b_colok && bn[j] < g.N && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
       const float* ptr = ok ? x + ((long)((bn[j] * g.H + hi) * g.W + wi) * g.ldx + ci0) : g_zero16;
       lds_dma16(ptr, b_dst + so + j * 1024);
-      bwo[j] += FBK;
+      bwo[j] += WBK;
       while (bwo[j] >= g.Wo) {
         bwo[j] -= g.Wo;
         if (++bho[j] == g.Ho) {
@@ -830,9 +863,9 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
       asm volatile("" ::: "memory");
       if (kc + 2 < nk) issue(nstage);
       const float* a = reinterpret_cast<const float*>(lds + stage * STAGE_B) + khalf * BM + wm * WTM + l31;
-      const float* b = reinterpret_cast<const float*>(lds + stage * STAGE_B) + FBK * BM + khalf * BN + wn * WTN + l31;
+      const float* b = reinterpret_cast<const float*>(lds + stage * STAGE_B) + WBK * BM + khalf * BN + wn * WTN + l31;
 #pragma unroll
-      for (int kk = 0; kk < FBK / 2; ++kk) {
+      for (int kk = 0; kk < WBK / 2; ++kk) {
         float av[TM], bv[TN];
 #pragma unroll
         for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * BM + t * 32];
@@ -846,24 +879,36 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
       if (want_bias) {
         const float* col = reinterpret_cast<const float*>(lds + stage * STAGE_B) + tid;
 #pragma unroll
-        for (int r = 0; r < FBK; ++r) bsum += col[r * BM];
+        for (int r = 0; r < WBK; ++r) bsum += col[r * BM];
       }
       stage = stage == 2 ? 0 : stage + 1;
       nstage = nstage == 2 ? 0 : nstage + 1;
     }
   }
 
+  // partial tile -> LDS (wave-private region of the idle ring) -> row-contiguous 16-byte stores
   float* out = partial + (size_t)split * g.K * g.Ktot;
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(lds) + wave * (32 * WTN);
+  constexpr int QPRW = WTN / 4;
+  constexpr int NRD = 32 * QPRW / 64;
 #pragma unroll
-  for (int u = 0; u < TN; ++u) {
-    const int n = n0 + wn * WTN + u * 32 + l31;
+  for (int t = 0; t < TM; ++t) {
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int u = 0; u < TN; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (m < g.K && n < g.Ktot) out[(size_t)m * g.Ktot + n] = acc[t][u][r];
-      }
+      for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + u * 32 + l31] = acc[t][u][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      const int idx = i * 64 + lane;
+      const int row = idx / QPRW, cq = idx - row * QPRW;
+      const float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+      const int m = m0 + wm * WTM + t * 32 + row;
+      const int n = n0 + wn * WTN + cq * 4;
+      if (m < g.K && n < g.Ktot) *reinterpret_cast<float4*>(out + (size_t)m * g.Ktot + n) = v;   // Ktot % 4 == 0
+    }
+    if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   if (want_bias && m0 + tid < g.K) bias_partial[(size_t)split * g.K + m0 + tid] = bsum;
 }
@@ -967,7 +1012,9 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
   // LDS-DMA kernels (g_fast_cfg 20 forces them off): no A-operand scaling, ablation flags or accumulate variants needed
   const int eflags = g.flags & 0xff;
-  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(eflags & SRHIP_EPI_CHANSCALE) && !(g.flags & 0x300) && g.K >= 64) {
+  const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                    (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(eflags & SRHIP_EPI_CHANSCALE) && !(g.flags & 0x300) && g.K >= 64 && al16) {
     const int nbm = cdiv(g.M, 128);
     const bool wide = g.K >= 128 && (long)nbm * cdiv(g.K, 128) >= 512;
     const long b64 = (long)nbm * cdiv(g.K, 64);
@@ -1079,7 +1126,7 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
 
 // ---- wgrad ------------------------------------------------------------------------------------- //
 struct FastWgradPlan {
-  int bm, bn, nsplit, chunks_per_split;
+  int bm, bn, bk, nsplit, chunks_per_split;
 };
 int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, +10: register-staged kernel
 static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
@@ -1088,8 +1135,10 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
   p.bn = (ktot % 128 == 0) ? 128 : 64;            // Ktot = 9*64 tiles exactly by 64, not by 128
   if (g_wgrad_cfg % 10 == 1) p.bn = 64;
   if (g_wgrad_cfg % 10 == 2) p.bn = 128;
+  p.bk = (g_wgrad_cfg == 3 || g_wgrad_cfg == 4) ? 32 : FBK;
+  if (g_wgrad_cfg == 4) p.bn = 64;
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
-  const int nchunks = cdiv(P, FBK);
+  const int nchunks = cdiv(P, p.bk);
   long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
   const long maxsplit = (nchunks + 15) / 16;          // at least 16 chunks (256 pixels) per split
   if (ns > maxsplit) ns = maxsplit;
@@ -1138,8 +1187,11 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
 #define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                            \
-    if (!xrow && !xchan && g_wgrad_cfg < 10)                                                                      \
-      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy,     \
+    if (!xrow && !xchan && g_wgrad_cfg < 10 && p.bk == 32)                                                        \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 32>), dim3(blocks), dim3(256), 0, st, x, dy, \
+                         partial, db ? bias_partial : nullptr, g);                                               \
+    else if (!xrow && !xchan && g_wgrad_cfg < 10)                                                                 \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16>), dim3(blocks), dim3(256), 0, st, x, dy, \
                          partial, db ? bias_partial : nullptr, g);                                               \
     else                                                                                                          \
       hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
