@@ -24,13 +24,32 @@ class _State:
     # a plain global, not threading.local: autograd runs Function.backward on its own device thread
     skip_param_grads = False
     direct_grads = False
+    skip_ids = frozenset()          # id()s of parameters whose gradients the current backward must not produce
+    stop_ids = frozenset()          # data_ptr()s of tensors the current backward must not propagate into
 
 
 _state = _State()
 
 
-def _skip_param_grads():
-    return _state.skip_param_grads
+def _skip_param_grads(*params):
+    """True when the running backward must not produce gradients for these parameters."""
+    if _state.skip_param_grads:
+        return True
+    return bool(_state.skip_ids) and any(p is not None and id(p) in _state.skip_ids for p in params)
+
+
+@contextlib.contextmanager
+def backward_scope(skip_params=(), stop_at=()):
+    """Prunes a backward pass that autograd cannot prune inside custom Functions: parameters listed in
+    `skip_params` get no weight gradient (their wgrad kernels are not launched), and the data gradient
+    is not propagated into the tensors listed in `stop_at`."""
+    prev = (_state.skip_ids, _state.stop_ids)
+    _state.skip_ids = frozenset(id(p) for p in skip_params)
+    _state.stop_ids = frozenset(t.data_ptr() for t in stop_at)
+    try:
+        yield
+    finally:
+        _state.skip_ids, _state.stop_ids = prev
 
 
 @contextlib.contextmanager
@@ -291,8 +310,9 @@ class _ConvFwd(Function):
     def backward(ctx, dy):
         x, w, y, b = ctx.saved_tensors
         g = dy if ctx.slope is None else _LReluBwd.apply(dy, y, ctx.slope)
-        skip = _skip_param_grads()
-        dx = _ConvDgrad.apply(g, w, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
+        skip = _skip_param_grads(w)
+        need_dx = ctx.needs_input_grad[0] and x.data_ptr() not in _state.stop_ids
+        dx = _ConvDgrad.apply(g, w, tuple(x.shape), ctx.stride, ctx.pad) if need_dx else None
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not skip
         if ctx.needs_input_grad[1] and not skip and _state.direct_grads and not torch.is_grad_enabled():
@@ -670,7 +690,23 @@ def batch_norm_act(x, bn, slope=None):
     y = _BNTrainFwd.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
     with torch.no_grad():
         bn.num_batches_tracked += 1
+    stash = getattr(bn, '_stat_stash', None)
+    if stash is not None and y.grad_fn is not None:
+        # (batch mean, invstd, count) of this call, so the caller can replay the running-statistics update
+        # of a forward pass it does not recompute (TrainStep: D(fake) == D(gen_hr))
+        x_, y_, g_, mean, invstd = y.grad_fn.saved_tensors
+        stash.append((bn, mean, invstd, x.numel() // x.shape[1]))
     return y
+
+
+def replay_bn_update(stash):
+    """Applies nn.BatchNorm2d's running-statistics update once more for every stashed (bn, mean, invstd, n)."""
+    with torch.no_grad():
+        for bn, mean, invstd, n in stash:
+            var = invstd.pow(-2) - bn.eps
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+            bn.num_batches_tracked += 1
 
 
 def max_pool2x2_raw(x):

@@ -36,7 +36,7 @@ def _ptr(t):
 class TrainStep:
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
-                 grad_sync=None, use_graph=False):
+                 grad_sync=None, use_graph=False, reuse_d_fake=True):
         self.G, self.D, self.F = generator, discriminator, feature_extractor
         self.weight_content, self.weight_gan = weight_content, weight_gan
         self.lambda_gp, self.clip_value, self.use_gp = lambda_gp, clip_value, use_gp
@@ -45,6 +45,8 @@ class TrainStep:
         self.arena_G, self.arena_D = ParamArena(self.G), ParamArena(self.D)
         self.grad_sync = grad_sync                       # dp.GradSync or None
         self.use_graph = use_graph
+        self.reuse_d_fake = reuse_d_fake
+        self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._calls = 0
         self._static = None
@@ -67,6 +69,8 @@ class TrainStep:
         return ops.gp_penalty(grads)
 
     def _compute(self, imgs_lr, imgs_hr, alpha):
+        if self.reuse_d_fake:
+            return self._compute_shared(imgs_lr, imgs_hr, alpha)
         G, D, F = self.G, self.D, self.F
         # ------------------ generator (sradsgan.py:829-857) ------------------
         self._set_d_grad(False)
@@ -92,6 +96,48 @@ class TrainStep:
             gp = torch.zeros((), device=imgs_hr.device)
             total = loss_D
         total.backward()
+        return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
+                    content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+
+    def _compute_shared(self, imgs_lr, imgs_hr, alpha):
+        """Same arithmetic, one discriminator forward fewer: D(gen_hr) of the G step (:847) and
+        D(gen_hr.detach()) of the D step (:877) see the same input and the same weights, so one graph
+        serves both -- the G-step backward walks it for d/d(gen_hr) only, the D-step backward for
+        d/d(theta_D) only.  The running statistics of BatchNorm receive the update of the skipped forward
+        at the position the reference applies it (after D(real))."""
+        G, D, F = self.G, self.D, self.F
+        g_params, d_params = self.arena_G.params, self.arena_D.params
+        self._set_d_grad(True)
+        self.arena_G.zero_grad()
+        self.arena_D.zero_grad()
+        gen_hr = G(imgs_lr)
+        pixel = ops.l1_mean(gen_hr, imgs_hr)
+        with torch.no_grad():
+            real_feat = F(imgs_hr)
+        content = ops.l1_mean(F(gen_hr), real_feat)
+        stash = []
+        for bn in self._bns:
+            bn._stat_stash = stash
+        d_gen = D(gen_hr)                                         # running-stat update #1
+        for bn in self._bns:
+            bn._stat_stash = None
+        loss_gan = -d_gen.mean()
+        loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
+        with ops.backward_scope(skip_params=d_params):            # no discriminator wgrads in the G step (:857 -> :865)
+            torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+        # ---------------- discriminator (sradsgan.py:865-886) ----------------
+        loss_D = -D(imgs_hr).mean() + d_gen.mean()                # update #2 (real)
+        ops.replay_bn_update(stash)                               # update #3 (the fake pass that is not recomputed)
+        fake = gen_hr.detach()
+        if self.use_gp:
+            gp = self.gradient_penalty(imgs_hr, fake, alpha)      # update #4
+            total = loss_D + (1.0 + self.lambda_gp) * gp          # :639 + :884-886 => 1 + lambda
+            loss_D = loss_D + self.lambda_gp * gp
+        else:
+            gp = torch.zeros((), device=imgs_hr.device)
+            total = loss_D
+        with ops.backward_scope(stop_at=(gen_hr,)):               # d/d(gen_hr) is not needed any more
+            torch.autograd.backward(total, inputs=d_params)
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
 
