@@ -1137,6 +1137,10 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
   if (g_wgrad_cfg % 10 == 2) p.bn = 128;
   p.bk = (g_wgrad_cfg == 3 || g_wgrad_cfg == 4) ? 32 : FBK;
   if (g_wgrad_cfg == 4) p.bn = 64;
+  if (g_wgrad_cfg == 5) {                              // 256-wide tiles: 32 MFMAs per wave per chunk for Cout=256 / Cout=64
+    if (cout % 256 == 0 && ktot % 64 == 0) { p.bm = 256; p.bn = 64; }
+    else if (cout == 64 && ktot % 256 == 0) { p.bm = 64; p.bn = 256; }
+  }
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
   const int nchunks = cdiv(P, p.bk);
   long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
@@ -1197,7 +1201,11 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
       hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
                          db ? bias_partial : nullptr, xrow, xchan, g);                                           \
   } while (0)
-  if (p.bm == 128 && p.bn == 128)
+  if (p.bm == 256 && p.bn == 64)
+    SRHIP_LW(256, 64, 4, 1);
+  else if (p.bm == 64 && p.bn == 256)
+    SRHIP_LW(64, 256, 1, 4);
+  else if (p.bm == 128 && p.bn == 128)
     SRHIP_LW(128, 128, 2, 2);
   else if (p.bm == 128)
     SRHIP_LW(128, 64, 2, 2);

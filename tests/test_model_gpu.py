@@ -219,3 +219,29 @@ def test_vgg_features_fused_forward_and_input_gradient():
     yh.backward(dy.to(DEV))
     _close(yh.detach().cpu(), yo.detach(), msg='features')
     _close(xh.grad.cpu(), xo.grad, msg='d/d(img)')
+
+
+def test_generator_inference_psnr_matches_oracle():
+    """BASELINE metric 'PSNR vs reference' (mfeNew_validate, sradsgan.py:1305-1325): full-size generator
+    (12 groups x 3 RAB, x4, 54 -> 216) on identical weights/inputs; output within 1e-3, and PSNR / MSE /
+    ERGAS of the uint8-quantised images (ToPILImage = mul(255).byte(), truncate + wrap) against a synthetic
+    HR target within 0.05 dB of the oracle's."""
+    from sradsgan_amd import model as M
+    og = O.GeneratorResNet(O.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=4)
+    O.det_init_(og, prefix='G.')
+    hg = M.GeneratorResNet(M.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=4)
+    hg.load_state_dict(og.state_dict(), strict=True)
+    hg.to(DEV).eval()
+    og.eval()
+    lr = O.det_fill('psnr.lr', (2, 3, 54, 54), 0.5, 0.5)
+    hr = O.det_fill('psnr.hr', (2, 3, 216, 216), 0.5, 0.5)
+    with torch.no_grad():
+        yo = og(lr)
+        yh = hg(lr.to(DEV)).cpu()
+    assert rel_err(yh, yo) < TOL
+    for b in range(2):
+        ref_img, hip_img, tgt = O.to_uint8_hwc(yo[b]), O.to_uint8_hwc(yh[b]), O.to_uint8_hwc(hr[b])
+        assert float(np.mean(ref_img != hip_img)) < 2e-3            # quantisation flips only at rounding boundaries
+        assert abs(O.psnr_u8(tgt, hip_img) - O.psnr_u8(tgt, ref_img)) < 0.05
+        assert abs(O.ergas2(tgt, hip_img) - O.ergas2(tgt, ref_img)) < 1e-2
+        assert abs(O.ssim_u8(tgt, hip_img) - O.ssim_u8(tgt, ref_img)) < 1e-3
