@@ -135,7 +135,9 @@ int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax,
  * fwd: batch mean / biased variance -> y = act((x-mean)*invstd*gamma + beta); updates
  * running_mean/var in place (momentum, unbiased variance) unless NULL; saves mean and invstd.
  * bwd: dy is the gradient at y; the activation mask comes from y; produces dx, dgamma, dbeta.
- * (The second-order pass needed by the gradient penalty :621,:639 is composed on the host side.)     */
+ * bwd_bwd: the second-order pass of the gradient penalty (:621,:639): for a cotangent ddx on dx it
+ * returns the gradients at dy (g_dy), at x (g_x) and at gamma (g_gamma); cotangents on dgamma/dbeta are
+ * not supported here (the host composes that rare case from primitive ops).                          */
 size_t srhip_bn_workspace(long rows, int c);
 int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
@@ -144,6 +146,11 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
 int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
                        size_t workspace_bytes, long rows, int c, float slope, int apply_act, void* stream);
+size_t srhip_bn_bwd2_workspace(long rows, int c);
+int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma,
+                           const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                           void* workspace, size_t workspace_bytes, long rows, int c, float slope, int apply_act,
+                           void* stream);
 
 /* ---- torch.optim.Adam (sradsgan.py:724-725, step at :858 and :887) over a flat fp32 arena, fused
  *      with the discriminator's weight clip `p.data.clamp_(-c, c)` (:891-892; clip <= 0: none).

@@ -40,6 +40,8 @@ SIGNATURES = {
     'srhip_bn_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_fwd': (_i, [_vp] * 9 + [_sz, _l, _i, _f, _f, _f, _i, _vp]),
     'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_bwd2_workspace': (_sz, [_l, _i]),
+    'srhip_bn_train_bwd_bwd': (_i, [_vp] * 11 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_adam_step': (_i, [_vp] * 5 + [_l] + [_f] * 6 + [_vp]),
 }
 

@@ -194,6 +194,132 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
   }
 }
 
+// ---- second-order pass (gradient penalty, sradsgan.py:621,639): backward of
+//      dx = a (dz - E[dz] - xhat E[dz xhat]),  a = gamma*invstd,  dz = dy * lrelu'(y)
+// for a cotangent u on dx.  With ubar = E[u], w = E[u xhat], p = E[dz], q = E[dz xhat], T = E[u dz] - ubar p - w q:
+//      d/d(dy)    = a (u - ubar - xhat w) * lrelu'(y)
+//      d/dx       = -gamma invstd^2 [ q (u - ubar) + w (dz - p) + xhat (T - 2 w q) ]
+//      d/dgamma   = invstd * N * T
+// stage 1 reduces the five per-channel sums, stage 2 turns them into coefficients, apply writes both tensors.
+__global__ __launch_bounds__(256) void bn_bwd2_stage1(const float* __restrict__ u, const float* __restrict__ dy,
+                                                      const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      float* __restrict__ partial, long rows, int c,
+                                                      long rows_per_block, float slope, int act) {
+  __shared__ float4 red[5][256];
+  const int tid = threadIdx.x;
+  const int q = c / 4, nrl = 256 / q;
+  const int cq = tid % q, rl = tid / q;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + cq * 4);
+  float4 s[5];
+  for (int k = 0; k < 5; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < nrl)
+    for (long r = r0 + rl; r < r1; r += nrl) {
+      const size_t o = (size_t)r * c + cq * 4;
+      const float4 uu = *reinterpret_cast<const float4*>(u + o);
+      float4 g = *reinterpret_cast<const float4*>(dy + o);
+      const float4 v = *reinterpret_cast<const float4*>(x + o);
+      if (act) {
+        const float4 yy = *reinterpret_cast<const float4*>(y + o);
+        g.x = yy.x > 0.f ? g.x : g.x * slope;
+        g.y = yy.y > 0.f ? g.y : g.y * slope;
+        g.z = yy.z > 0.f ? g.z : g.z * slope;
+        g.w = yy.w > 0.f ? g.w : g.w * slope;
+      }
+      const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
+      s[0] = f4add(s[0], uu);
+      s[1] = f4add(s[1], make_float4(uu.x * xh.x, uu.y * xh.y, uu.z * xh.z, uu.w * xh.w));
+      s[2] = f4add(s[2], g);
+      s[3] = f4add(s[3], make_float4(g.x * xh.x, g.y * xh.y, g.z * xh.z, g.w * xh.w));
+      s[4] = f4add(s[4], make_float4(uu.x * g.x, uu.y * g.y, uu.z * g.z, uu.w * g.w));
+    }
+  for (int k = 0; k < 5; ++k) red[k][tid] = s[k];
+  __syncthreads();
+  if (tid < q) {
+    for (int k = 0; k < 5; ++k) {
+      float4 a = s[k];
+      for (int j = 1; j < nrl; ++j) a = f4add(a, red[k][j * q + tid]);
+      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * 5 + k) * c + tid * 4) = a;
+    }
+  }
+}
+
+// coef[0..4][c] = ubar, w, p, q, T ; dgamma2[c] = invstd * N * T
+__global__ void bn_bwd2_stage2(const float* __restrict__ partial, const float* __restrict__ invstd,
+                               float* __restrict__ coef, float* __restrict__ dgamma2, int nblk, int c, long rows) {
+  __shared__ float r[5][256];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (col < c)
+    for (int k = sub; k < nblk; k += 16)
+      for (int j = 0; j < 5; ++j) a[j] += partial[((size_t)k * 5 + j) * c + col];
+  for (int j = 0; j < 5; ++j) r[j][threadIdx.x] = a[j];
+  __syncthreads();
+  if (sub == 0 && col < c) {
+    float t[5];
+    for (int j = 0; j < 5; ++j) {
+      float v = 0.f;
+      for (int k = 0; k < 16; ++k) v += r[j][threadIdx.x + 16 * k];
+      t[j] = v;
+    }
+    const float n = (float)rows;
+    const float ubar = t[0] / n, w = t[1] / n, p = t[2] / n, q = t[3] / n;
+    const float T = t[4] / n - ubar * p - w * q;
+    coef[0 * c + col] = ubar;
+    coef[1 * c + col] = w;
+    coef[2 * c + col] = p;
+    coef[3 * c + col] = q;
+    coef[4 * c + col] = T;
+    dgamma2[col] = invstd[col] * n * T;
+  }
+}
+
+__global__ void bn_bwd2_apply_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                     const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ coef,
+                                     float* __restrict__ g_dy, float* __restrict__ g_x, long n4, int c, float slope,
+                                     int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const int ch = (int)((i * 4) % c);
+    const float4 uu = reinterpret_cast<const float4*>(u)[i];
+    const float4 g0 = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act) {
+      const float4 yy = reinterpret_cast<const float4*>(y)[i];
+      mk = make_float4(yy.x > 0.f ? 1.f : slope, yy.y > 0.f ? 1.f : slope, yy.z > 0.f ? 1.f : slope,
+                       yy.w > 0.f ? 1.f : slope);
+    }
+    const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+    const float4 ub = *reinterpret_cast<const float4*>(coef + ch);
+    const float4 ww = *reinterpret_cast<const float4*>(coef + c + ch);
+    const float4 pp = *reinterpret_cast<const float4*>(coef + 2 * c + ch);
+    const float4 qq = *reinterpret_cast<const float4*>(coef + 3 * c + ch);
+    const float4 TT = *reinterpret_cast<const float4*>(coef + 4 * c + ch);
+    float4 od, ox;
+#define SRHIP_BN2(F)                                                                                     \
+  {                                                                                                      \
+    const float xh = (v.F - mu.F) * is.F;                                                                \
+    const float dz = g0.F * mk.F;                                                                        \
+    od.F = ga.F * is.F * (uu.F - ub.F - xh * ww.F) * mk.F;                                               \
+    ox.F = -ga.F * is.F * is.F *                                                                         \
+           (qq.F * (uu.F - ub.F) + ww.F * (dz - pp.F) + xh * (TT.F - 2.f * ww.F * qq.F));                \
+  }
+    SRHIP_BN2(x) SRHIP_BN2(y) SRHIP_BN2(z) SRHIP_BN2(w)
+#undef SRHIP_BN2
+    reinterpret_cast<float4*>(g_dy)[i] = od;
+    reinterpret_cast<float4*>(g_x)[i] = ox;
+  }
+}
+
 static long bn_nblk(long rows) {
   long nblk = (rows + 63) / 64;
   return nblk > 256 ? 256 : (nblk < 1 ? 1 : nblk);
@@ -249,6 +375,32 @@ int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const fl
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, gamma, dgamma,
                      dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act);
   return check_launch("bn_train_bwd");
+}
+
+size_t srhip_bn_bwd2_workspace(long rows, int c) { return ((size_t)bn_nblk(rows) * 5 * c + 5 * (size_t)c) * sizeof(float); }
+
+int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma,
+                           const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                           void* workspace, size_t workspace_bytes, long rows, int c, float slope, int apply_act,
+                           void* stream) {
+  SRHIP_REQUIRE(ddx && dy && x && gamma && save_mean && save_invstd && g_dy && g_x && g_gamma && (y || !apply_act),
+                "bn_train_bwd_bwd: null tensor");
+  SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_bwd_bwd: C must be a multiple of 4, <= 1024");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_bn_bwd2_workspace(rows, c), "bn_train_bwd_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const long nblk = bn_nblk(rows), rpb = (rows + nblk - 1) / nblk;
+  float* part = static_cast<float*>(workspace);
+  float* coef = part + (size_t)nblk * 5 * c;
+  hipLaunchKernelGGL(bn_bwd2_stage1, dim3((int)nblk), dim3(256), 0, st, ddx, dy, x, y, save_mean, save_invstd, part, rows,
+                     c, rpb, slope, apply_act);
+  hipLaunchKernelGGL(bn_bwd2_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, save_invstd, coef, g_gamma, (int)nblk, c,
+                     rows);
+  const long n4 = rows * c / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bn_bwd2_apply_kernel, dim3(blocks), dim3(256), 0, st, ddx, dy, x, y, save_mean, save_invstd, gamma,
+                     coef, g_dy, g_x, n4, c, slope, apply_act);
+  return check_launch("bn_train_bwd_bwd");
 }
 
 }  // extern "C"

@@ -641,12 +641,29 @@ class _BNTrainBwd(Function):
                                           _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, rows, c,
                                           float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
         ctx.eps, ctx.slope = eps, slope
-        ctx.save_for_backward(dy, x, y, gamma)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(dy, x, y, gamma, mean, invstd)
         return dx, dgamma, dbeta
 
     @staticmethod
     def backward(ctx, ddx, ddgamma, ddbeta):
-        dy, x, y, gamma = ctx.saved_tensors
+        dy, x, y, gamma, mean, invstd = ctx.saved_tensors
+        if ddx is None and ddgamma is None and ddbeta is None:
+            return (None,) * 8
+        if ddx is not None and ddgamma is None and ddbeta is None and not torch.is_grad_enabled():
+            # the gradient-penalty case: one fused second-order pass (3 launches instead of ~40 ATen ops)
+            uc, dyc, xc, yc = nhwc(ddx), nhwc(dy), nhwc(x), nhwc(y)
+            n, c, h, w = x.shape
+            rows = n * h * w
+            lib = _hip.lib()
+            g_dy, g_x = torch.empty_like(xc, memory_format=CL), torch.empty_like(xc, memory_format=CL)
+            g_gamma = torch.empty_like(gamma)
+            ws = torch.empty(lib.srhip_bn_bwd2_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
+            _hip.check(lib.srhip_bn_train_bwd_bwd(_p(uc), _p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()),
+                                                  _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(ws),
+                                                  ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
+                                                  int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
+            return g_dy, g_x, None, g_gamma, None, None, None, None
         with torch.enable_grad():
             dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
             outs = _bn_reference_bwd(dy_, x_, y, g_, ctx.eps, ctx.slope)
