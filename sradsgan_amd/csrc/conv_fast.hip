@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ residual,
                                                              const float* __restrict__ rowscale,
+                                                             const float* __restrict__ chanscale,
                                                              const float* __restrict__ actmask,
                                                              float* __restrict__ dst, FastGeom g, int nblk_m,
                                                              int nblk_n) {
@@ -414,6 +415,18 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
+  // A-operand channel scale (CLAM's s folded into the attention tail's 1x1 conv): fragment value
+  // A[row][k] *= chanscale[image(row)][channel(k)], applied to the registers right after the LDS read
+  const bool cscale = ((EPI >= 0 ? EPI : g.flags) & SRHIP_EPI_CHANSCALE) != 0;
+  const float* csrow[TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int m = m0 + wm * WTM + t * 32 + l31;
+    csrow[t] = chanscale + (size_t)((m < g.M ? m : 0) / OHOW) * g.C + khalf * 4;
+  }
+  const int T_taps = g.TH * g.TW;
+  int c_tap = 0, c_cc = 0;                           // compute-side position in the (cc, tap) loop nest
+
   if (nk > 0) {
     issue(0);
     if (nk > 1) issue(1);
@@ -436,6 +449,22 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
       for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ 32));
 #pragma unroll
       for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ 32));
+      if (cscale) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            const float4 sc = *reinterpret_cast<const float4*>(csrow[t] + c_cc * BK + ks * 8);
+            af[ks][t].x *= sc.x;
+            af[ks][t].y *= sc.y;
+            af[ks][t].z *= sc.z;
+            af[ks][t].w *= sc.w;
+          }
+        if (++c_tap == T_taps) {
+          c_tap = 0;
+          ++c_cc;
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -1014,16 +1043,18 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   const int eflags = g.flags & 0xff;
   const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
-  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(eflags & SRHIP_EPI_CHANSCALE) && !(g.flags & 0x300) && g.K >= 64 && al16) {
+  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+      (!(eflags & SRHIP_EPI_CHANSCALE) || ((uintptr_t)chanscale & 15) == 0)) {
     const int nbm = cdiv(g.M, 128);
-    const bool wide = g.K >= 128 && (long)nbm * cdiv(g.K, 128) >= 512;
+    const bool force = g_fast_cfg == -1;                 // tests: take the DMA kernels at any problem size
+    const bool wide = g.K >= 128 && ((long)nbm * cdiv(g.K, 128) >= 512 || force);
     const long b64 = (long)nbm * cdiv(g.K, 64);
-    if (wide || b64 >= 512) {
+    if (wide || b64 >= 512 || force) {
 #define SRHIP_LD(BN_, EPI_)                                                                                        \
   do {                                                                                                             \
     const int nbn = cdiv(g.K, BN_);                                                                                \
     hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src, \
-                       wt, bias, residual, rowscale, actmask, dst, g, nbm, nbn);                                   \
+                       wt, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                        \
     return check_launch("fast_conv_dma");                                                                          \
   } while (0)
 #define SRHIP_LDE(BN_)                                                  \
@@ -1034,6 +1065,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     if (eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_LD(BN_, 3); \
     if (eflags == SRHIP_EPI_ACTMASK) SRHIP_LD(BN_, 32);                 \
     if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LD(BN_, 4);                 \
+    if (eflags == 29) SRHIP_LD(BN_, 29); /* bias|residual|rowscale|chanscale: the attention tail */ \
     SRHIP_LD(BN_, -1);                                                  \
   } while (0)
       if (wide) SRHIP_LDE(128);

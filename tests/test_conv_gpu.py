@@ -186,3 +186,38 @@ def test_batch_norm_lrelu_fwd_bwd_double_bwd(shape):
     for name, a, b in zip(('y', 'dx', 'ddx', 'dgamma', 'dbeta', 'running_mean', 'running_var'), got, ref):
         assert _rel(a, b) < 2e-4, name
     assert int(got[7]) == int(ref[7]) == 1
+
+
+@pytest.fixture
+def force_dma():
+    """The LDS-DMA conv kernels are normally chosen only for >= 512 tiles; force them for small test shapes."""
+    from sradsgan_amd import _hip
+    _hip.lib().srhip_debug_set(0, -1)
+    yield
+    _hip.lib().srhip_debug_set(0, 0)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 12, 10, 256, 3, 1, 1), (2, 256, 12, 10, 64, 3, 1, 1), (1, 64, 54, 54, 64, 1, 1, 0),
+                                  (2, 64, 16, 16, 64, 3, 2, 1), (2, 128, 27, 27, 128, 3, 2, 1), (2, 64, 6, 7, 576, 3, 1, 1),
+                                  (3, 128, 9, 13, 192, 3, 1, 1)])
+def test_dma_conv_kernels_small_shapes(case, force_dma):
+    test_conv_fwd_bwd_matches_torch(case)
+
+
+def test_dma_conv_fused_epilogues(force_dma):
+    """residual add, activation mask (backward of the producer's LeakyReLU) and channel/row scaling on
+    the LDS-DMA kernels."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(123)
+    n, h, w = 2, 11, 13
+    # dgrad with activation mask + residual: dx = conv_transpose(dy, w) * lrelu'(t) + r
+    dy = torch.randn(n, 64, h, w, generator=g)
+    wt = torch.randn(64, 256, 3, 3, generator=g) * 0.05          # conv 256 -> 64, so dgrad produces 256 channels
+    t = torch.randn(n, 256, h, w, generator=g)
+    r = torch.randn(n, 256, h, w, generator=g)
+    ref = torch.nn.grad.conv2d_input((n, 256, h, w), wt, dy, padding=1) * torch.where(t > 0, 1.0, 0.2) + r
+    got = ops.conv2d_dgrad_raw(dy.to(dev), wt.to(dev), (n, 256, h, w), 1, 1, r.to(dev), t.to(dev), 0.2)
+    assert _rel(got, ref) < TOL
+    test_conv_operand_scaling()
+    test_conv_residual_epilogue()
