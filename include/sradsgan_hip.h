@@ -48,6 +48,12 @@ int srhip_debug_set(int key, int value);
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode);
 int srhip_pack_weight(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw, int mode,
                       void* stream);
+/* Batched form: one launch re-packs `count` weights.  entries_dev: device array of
+ * struct { const float* w; float* packed; int cout, cin, kh, kw, mode, fast; } (srhip_pack_entry_bytes()
+ * bytes each; fast = srhip_packed_is_fast(cout, cin, kh, kw, mode)).                                */
+int srhip_pack_entry_bytes(void);
+int srhip_packed_is_fast(int cout, int cin, int kh, int kw, int mode);
+int srhip_pack_weights_batched(const void* entries_dev, int count, void* stream);
 
 /* ---- nn.Conv2d forward (sradsgan.py:222-223,233,297,332-336,375,381,384,427,448,476,503;
  *      vgg19.features convs :92-95) with the elementwise tail of its call site fused:

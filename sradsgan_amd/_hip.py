@@ -17,6 +17,9 @@ SIGNATURES = {
     'srhip_abi_version': (_i, []),
     'srhip_debug_set': (_i, [_i, _i]),
     'srhip_packed_elems': (_sz, [_i] * 5),
+    'srhip_pack_entry_bytes': (_i, []),
+    'srhip_packed_is_fast': (_i, [_i] * 5),
+    'srhip_pack_weights_batched': (_i, [_vp, _i, _vp]),
     'srhip_pack_weight': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'srhip_conv2d_fwd': (_i, [_vp] * 7 + [_i] * 12 + [_f, _i, _vp]),
     'srhip_conv2d_dgrad': (_i, [_vp] * 5 + [_f] + [_i] * 13 + [_vp]),

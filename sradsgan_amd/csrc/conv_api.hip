@@ -6,6 +6,53 @@
 using namespace srhip;
 
 namespace srhip {
+// one launch re-packs every registered conv weight of a network (after each optimiser step):
+// blockIdx.y = entry, blockIdx.x strides over the packed elements
+struct PackEntry {
+  const float* w;
+  float* packed;
+  int cout, cin, kh, kw, mode, fast;
+};
+__global__ void pack_batched_kernel(const PackEntry* __restrict__ tab) {
+  const PackEntry e = tab[blockIdx.y];
+  const int khkw = e.kh * e.kw;
+  if (e.fast) {
+    const long total = (long)e.cout * e.cin * khkw;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      if (e.mode == 0) {
+        const int co = (int)(idx / (khkw * e.cin));
+        const int rem = (int)(idx - (long)co * khkw * e.cin);
+        const int tap = rem / e.cin, ci = rem - tap * e.cin;
+        e.packed[idx] = e.w[((size_t)co * e.cin + ci) * khkw + tap];
+      } else {
+        const int ci = (int)(idx / (khkw * e.cout));
+        const int rem = (int)(idx - (long)ci * khkw * e.cout);
+        const int tap = rem / e.cout, co = rem - tap * e.cout;
+        e.packed[idx] = e.w[((size_t)co * e.cin + ci) * khkw + tap];
+      }
+    }
+  } else {
+    const int csrc = e.mode == 0 ? e.cin : e.cout, cdst = e.mode == 0 ? e.cout : e.cin;
+    const int ld = ((cdst + 31) / 32) * 32;
+    const long total = (long)khkw * csrc * ld;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      const int row = (int)(idx / ld), col = (int)(idx - (long)row * ld);
+      float v = 0.f;
+      if (col < cdst) {
+        const int tap = row / csrc, cs = row - tap * csrc;
+        const int a = tap / e.kw, b = tap - a * e.kw;
+        if (e.mode == 0)
+          v = e.w[(((size_t)col * e.cin + cs) * e.kh + a) * e.kw + b];
+        else
+          v = e.w[(((size_t)cs * e.cin + col) * e.kh + (e.kh - 1 - a)) * e.kw + (e.kw - 1 - b)];
+      }
+      e.packed[idx] = v;
+    }
+  }
+}
+}  // namespace srhip
+
+namespace srhip {
 extern int g_fast_cfg;
 extern int g_wgrad_cfg;
 extern int g_fast_dynlds;
@@ -41,6 +88,20 @@ size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode) {
   if (fast) return (size_t)cout * cin * kh * kw;
   const int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
   return (size_t)kh * kw * csrc * legacy_packed_ld(cdst);
+}
+
+int srhip_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
+
+int srhip_packed_is_fast(int cout, int cin, int kh, int kw, int mode) {
+  return (mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw)) ? 1 : 0;
+}
+
+int srhip_pack_weights_batched(const void* entries_dev, int count, void* stream) {
+  SRHIP_REQUIRE(entries_dev && count >= 0, "pack_weights_batched: bad argument");
+  if (count == 0) return SRHIP_OK;
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(32, count), dim3(256), 0, as_stream(stream),
+                     static_cast<const PackEntry*>(entries_dev));
+  return check_launch("pack_weights_batched");
 }
 
 int srhip_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, void* stream) {

@@ -11,6 +11,7 @@ No CPU path exists: a CPU tensor raises.
 import contextlib
 import ctypes
 import threading
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -120,33 +121,92 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_pack_epoch = [0]
+class _PackRegistry:
+    """Persistent packed images of trainable conv weights.  Each (Parameter, mode) gets ONE buffer that is
+    rewritten in place: by a single batched launch after every optimiser step (repack_all, called from
+    bump_weight_epoch) instead of ~280 tiny pack launches scattered through the next iteration."""
+
+    def __init__(self):
+        self.entries = []        # [weakref(w), mode, packed, data_ptr, version]
+        self.table = None
+        self.dirty = True
+
+
+_registry = _PackRegistry()
+
+
+def _pack_now(w, mode, packed):
+    cout, cin, kh, kw = w.shape
+    wd = w.detach().contiguous()
+    _hip.check(_hip.lib().srhip_pack_weight(_p(wd), _p(packed), cout, cin, kh, kw, mode, _stream()), 'pack_weight')
+
+
+def repack_all():
+    reg = _registry
+    if any(ent[0]() is None for ent in reg.entries):            # parameters of discarded models
+        reg.entries = [ent for ent in reg.entries if ent[0]() is not None]
+        reg.dirty = True
+    if not reg.entries:
+        return
+    lib = _hip.lib()
+    live = [ent[0]() for ent in reg.entries]
+    if reg.dirty or reg.table is None:
+        import struct
+        assert lib.srhip_pack_entry_bytes() == 40
+        blob = bytearray()
+        for ent, w in zip(reg.entries, live):
+            mode, packed = ent[1], ent[2]
+            cout, cin, kh, kw = w.shape
+            fast = lib.srhip_packed_is_fast(cout, cin, kh, kw, mode)
+            blob += struct.pack('<QQiiiiii', w.data_ptr(), packed.data_ptr(), cout, cin, kh, kw, mode, fast)
+            ent[3] = w.data_ptr()
+        reg.table = torch.frombuffer(blob, dtype=torch.uint8).to(live[0].device)
+        reg.dirty = False
+    _hip.check(lib.srhip_pack_weights_batched(_p(reg.table), len(reg.entries), _stream()), 'pack_weights_batched')
+    for ent, w in zip(reg.entries, live):
+        ent[4] = w._version
 
 
 def bump_weight_epoch():
-    """Called by the fused optimiser (it updates parameters through raw pointers, which does not
-    bump tensor._version) so cached packed weights are rebuilt."""
-    _pack_epoch[0] += 1
+    """Called by the fused optimiser (it updates parameters through raw pointers, which does not bump
+    tensor._version): re-packs every registered conv weight in one launch."""
+    repack_all()
+
+
+def mark_static(module):
+    """Parameters of `module` are never updated (VGG): pack once, keep out of the per-step batched repack."""
+    for p in module.parameters():
+        p._srhip_static = True
 
 
 def packed_weight(w, mode):
-    """OIHW parameter -> GEMM operand (srhip_pack_weight).  Cached per Parameter until it changes."""
+    """OIHW weight -> GEMM operand.  Parameters get a persistent buffer (see _PackRegistry); other tensors
+    (e.g. the weight cotangent of a second-order pass) are packed on the fly."""
     cout, cin, kh, kw = w.shape
-    key = (mode, w._version, _pack_epoch[0], w.data_ptr())
-    cacheable = isinstance(w, torch.nn.Parameter)
-    if cacheable:
-        ent = getattr(w, '_srhip_packed', None)
-        if ent is not None and ent.get(mode, (None, None))[0] == key:
-            return ent[mode][1]
-    wd = w.detach().contiguous()
     lib = _hip.lib()
-    packed = torch.empty(lib.srhip_packed_elems(cout, cin, kh, kw, mode), device=w.device, dtype=torch.float32)
-    _hip.check(lib.srhip_pack_weight(_p(wd), _p(packed), cout, cin, kh, kw, mode, _stream()), 'pack_weight')
-    if cacheable:
-        if getattr(w, '_srhip_packed', None) is None:
-            w._srhip_packed = {}
-        w._srhip_packed[mode] = (key, packed)
-    return packed
+    if not isinstance(w, torch.nn.Parameter):
+        packed = torch.empty(lib.srhip_packed_elems(cout, cin, kh, kw, mode), device=w.device, dtype=torch.float32)
+        _pack_now(w, mode, packed)
+        return packed
+    slots = getattr(w, '_srhip_packed', None)
+    if slots is None:
+        slots = w._srhip_packed = {}
+    ent = slots.get(mode)
+    if ent is None or ent[3] != w.data_ptr():
+        packed = torch.empty(lib.srhip_packed_elems(cout, cin, kh, kw, mode), device=w.device, dtype=torch.float32)
+        _pack_now(w, mode, packed)
+        new = [weakref.ref(w), mode, packed, w.data_ptr(), w._version]
+        if ent is not None and ent in _registry.entries:
+            _registry.entries.remove(ent)
+        slots[mode] = new
+        if not getattr(w, '_srhip_static', False):
+            _registry.entries.append(new)
+            _registry.dirty = True
+        return packed
+    if ent[4] != w._version:                       # changed by a torch op (load_state_dict, torch optimiser, ...)
+        _pack_now(w, mode, ent[2])
+        ent[4] = w._version
+    return ent[2]
 
 
 def _out_hw(h, w, k, stride, pad):

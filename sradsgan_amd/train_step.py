@@ -53,6 +53,7 @@ class TrainStep:
         self._d_params = self.arena_D.params
         for p in self.F.parameters():
             p.requires_grad_(False)                      # never in an optimiser (sradsgan.py:724-725)
+        ops.mark_static(self.F)
 
     # ------------------------------------------------------------------------------------------ #
     def _set_d_grad(self, flag):
