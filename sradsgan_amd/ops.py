@@ -25,6 +25,7 @@ class _State:
     # a plain global, not threading.local: autograd runs Function.backward on its own device thread
     skip_param_grads = False
     direct_grads = False
+    wgrad_stream = None             # side HIP stream for weight-gradient kernels (direct_param_grads mode only)
     skip_ids = frozenset()          # id()s of parameters whose gradients the current backward must not produce
     stop_ids = frozenset()          # data_ptr()s of tensors the current backward must not propagate into
 
@@ -67,18 +68,18 @@ def no_param_grads():
 
 
 @contextlib.contextmanager
-def direct_param_grads():
+def direct_param_grads(side_stream=None):
     """Inside this context the fused backward kernels ACCUMULATE parameter gradients straight into the
     parameters' existing .grad buffers (the gradient arena of dp.ParamArena) and hand autograd None for
     them: one wgrad launch per conv instead of wgrad + one `grad += new` launch per parameter
     (~600 tiny launches per step).  Only valid when every such parameter already owns a dense .grad
     and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
-    prev = _state.direct_grads
-    _state.direct_grads = True
+    prev = (_state.direct_grads, _state.wgrad_stream)
+    _state.direct_grads, _state.wgrad_stream = True, side_stream
     try:
         yield
     finally:
-        _state.direct_grads = prev
+        _state.direct_grads, _state.wgrad_stream = prev
 
 
 def _grad_slot(p):
@@ -295,7 +296,21 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
     gb = _grad_slot(b) if (want_b and b is not None) else None
     if gw is not None and (not want_b or gb is not None) and \
             _hip.lib().srhip_conv2d_wgrad_can_accumulate(cin, cout, kh, kw):
-        conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+        side = _state.wgrad_stream
+        if side is None:
+            conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+            return None, None
+        # Weight gradients are off the critical path of backward (nothing reads them before the optimiser):
+        # run them on a side stream so the partially filled last wave of each data-gradient kernel and of
+        # each wgrad kernel overlap.  Same-parameter accumulations stay ordered (one side stream).
+        x, dy = nhwc(x), nhwc(dy)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+        for t in (x, dy, xrowscale, xchanscale):
+            if t is not None:
+                t.record_stream(side)
         return None, None
     return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
 
@@ -397,10 +412,12 @@ class _ConvDgrad(Function):
     @staticmethod
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
-        skip = _skip_param_grads()
+        skip = _skip_param_grads(w)
         d_dy = _ConvFwd.apply(ddx, w, None, None, ctx.stride, ctx.pad, None) if ctx.needs_input_grad[0] else None
         d_w = None
-        if ctx.needs_input_grad[1] and not skip:
+        if ctx.needs_input_grad[1] and not skip and _state.direct_grads and not torch.is_grad_enabled():
+            d_w, _ = wgrad_for_params(w, None, ddx, dy, ctx.stride, ctx.pad, False)   # same stream/order as every other wgrad of w
+        elif ctx.needs_input_grad[1] and not skip:
             d_w, _ = _ConvWgrad.apply(ddx, dy, tuple(w.shape), ctx.stride, ctx.pad, False)
         return d_dy, d_w, None, None, None
 

@@ -36,7 +36,7 @@ def _ptr(t):
 class TrainStep:
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
-                 grad_sync=None, use_graph=False, reuse_d_fake=True):
+                 grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True):
         self.G, self.D, self.F = generator, discriminator, feature_extractor
         self.weight_content, self.weight_gan = weight_content, weight_gan
         self.lambda_gp, self.clip_value, self.use_gp = lambda_gp, clip_value, use_gp
@@ -46,6 +46,9 @@ class TrainStep:
         self.grad_sync = grad_sync                       # dp.GradSync or None
         self.use_graph = use_graph
         self.reuse_d_fake = reuse_d_fake
+        self.overlap_wgrad = overlap_wgrad
+        dev = self.arena_G.flat_p.device
+        self._wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._calls = 0
@@ -175,8 +178,13 @@ class TrainStep:
     def __call__(self, imgs_lr, imgs_hr, alpha):
         self._calls += 1
         if not self.use_graph:
-            with ops.direct_param_grads():           # wgrad kernels accumulate straight into the gradient arenas
+            side = self._wgrad_stream if self.overlap_wgrad else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())     # arena zeroing / previous Adam before any wgrad
+            with ops.direct_param_grads(side):       # wgrad kernels accumulate straight into the gradient arenas
                 out = self._compute(imgs_lr, imgs_hr, alpha)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update
             self._update()
             return out
         if self._calls == 1:
