@@ -114,10 +114,22 @@ class TrainStep:
         self._set_d_grad(True)
         self.arena_G.zero_grad()
         self.arena_D.zero_grad()
+        side = self._wgrad_stream if (self.overlap_wgrad and not self.use_graph) else None
+        if side is not None:
+            # VGG features of the real batch depend on nothing the generator produces: compute them on the
+            # side stream while the generator's forward runs (fills the partially occupied kernel tails)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                real_feat = F(imgs_hr)
+            imgs_hr.record_stream(side)
         gen_hr = G(imgs_lr)
         pixel = ops.l1_mean(gen_hr, imgs_hr)
-        with torch.no_grad():
-            real_feat = F(imgs_hr)
+        if side is None:
+            with torch.no_grad():
+                real_feat = F(imgs_hr)
+        else:
+            torch.cuda.current_stream().wait_stream(side)
+            real_feat.record_stream(torch.cuda.current_stream())   # allocated in the side stream's pool, read here
         content = ops.l1_mean(F(gen_hr), real_feat)
         stash = []
         for bn in self._bns:
