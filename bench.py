@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='(default) launch every kernel eagerly')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--roofline-only', action='store_true',
+                    help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
     ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
     return ap.parse_args()
 
@@ -205,6 +207,9 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
+    if args.roofline_only:
+        print(json.dumps({'roofline': time_dominant_kernel(device, args.batch)}), flush=True)
+        return
     from sradsgan_amd.train_step import TrainStep
     from sradsgan_amd import dp
     B = args.batch
