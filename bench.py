@@ -25,6 +25,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the step overlaps two HIP streams (train_step.py); ROCm multiplexes streams onto a few hardware queues and
+# RCCL adds its own -- keep enough queues that the two compute streams never share one (measured: sharing
+# costs 10 % of the step).  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PER_GPU_BATCH = 32
 SCALE, LR_SIDE = 4, 54
@@ -203,9 +207,13 @@ def main():
     _hip.lib()                                               # fail loudly if the extension is missing
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = os.environ.get('BENCH_FORCE_DIST') == '1'      # debug: RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        # no device_id: the communicator (and RCCL's own streams) is then created at the first collective,
+        # after the step's compute streams exist and own their hardware queues
+        dist.init_process_group('nccl', rank=rank, world_size=world)
 
     if args.roofline_only:
         print(json.dumps({'roofline': time_dominant_kernel(device, args.batch)}), flush=True)
@@ -214,7 +222,7 @@ def main():
     from sradsgan_amd import dp
     B = args.batch
     G, D, F = build_networks(device, seed=20240)             # identical initial replicas on every rank
-    sync = dp.GradSync(world) if world > 1 else None
+    sync = dp.GradSync(world, force=force_dist) if (world > 1 or force_dist) else None
     step = TrainStep(G, D, F, grad_sync=sync, use_graph=args.graph and not args.no_graph,
                      use_gp=os.environ.get('BENCH_NO_GP') != '1')
     gen = torch.Generator().manual_seed(1234 + rank)         # disjoint synthetic shards per rank
@@ -223,7 +231,7 @@ def main():
     alpha = torch.rand(B, 1, 1, 1, generator=gen).to(device)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -274,7 +282,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -67,8 +67,9 @@ class GradSync:
     """Mean of a gradient arena over the ranks: bucketed in-place all-reduce(SUM), asynchronous per
     bucket, then one scale by 1/world (folded into the Adam kernel by the caller when it can)."""
 
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, force=False):
         self.group = group
+        self.force = force           # run the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
 
@@ -79,7 +80,7 @@ class GradSync:
     def start(self, flat):
         """Launch the all-reduces; returns handles for finish().  `flat` must be the gradient arena
         (contiguous 1-D).  With world == 1 this is a no-op."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return []
         if not dist.is_initialized():
             raise RuntimeError('GradSync: torch.distributed is not initialised')

@@ -167,7 +167,13 @@ class TrainStep:
     def _update(self):
         """exchange + update: sradsgan.py:858 (optimizer_G.step), :887 (optimizer_D.step), :891-892 (clip)."""
         scale = 1.0
-        if self.grad_sync is not None and self.grad_sync.world > 1:
+        if self.grad_sync is not None and (self.grad_sync.world > 1 or getattr(self.grad_sync, 'force', False)):
+            if os.environ.get('SRHIP_DP_HOST_SYNC', '1') == '1':
+                # Enqueue the collectives only once the GPU has actually finished the backward pass.  Measured on
+                # MI355X / ROCm 7.2 / RCCL 2.26: an all-reduce enqueued ~100 ms ahead of its inputs (a wait on the
+                # compute stream parked at the head of RCCL's queue) slows the whole queued step by 8-56 ms even
+                # for a 64-byte payload; with the host sync the exchange costs what the wire costs.
+                torch.cuda.current_stream().synchronize()
             handles = self.grad_sync.start(self.arena_G.flat_g) + self.grad_sync.start(self.arena_D.flat_g)
             self.grad_sync.finish(handles)
             scale = self.grad_sync.grad_scale
