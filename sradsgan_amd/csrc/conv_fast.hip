@@ -1040,7 +1040,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
   if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
   // LDS-DMA kernels (g_fast_cfg 20 forces them off): no A-operand scaling, ablation flags or accumulate variants needed
-  const int eflags = g.flags & 0xff;
+  const int eflags = g.flags & 0xff;      // bits 0x100/0x200: ablations (reg kernel), 0x400: s_setprio experiment
   const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
