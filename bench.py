@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='(default) launch every kernel eagerly')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--workload', choices=['train', 'infer'], default='train',
+                    help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]; not the headline line)")
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
     ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
@@ -170,6 +172,34 @@ def cpu_baseline(iters, budget_s=60.0):
                       'oracle/sradsgan_ref.train_step on torch CPU ops, median' % len(ts)}
 
 
+def run_inference(args, device):
+    """BASELINE configs[1]: SRADSGAN generator-only x4 inference (mfeNew_validate's G forward, sradsgan.py:1305)
+    followed by the device-side validation metrics; batch 16 unless --batch is given."""
+    import torch
+    from sradsgan_amd import validate
+    B = 16 if args.batch == PER_GPU_BATCH else args.batch
+    G, _, _ = build_networks(device, seed=20240)
+    G.eval()
+    gen = torch.Generator().manual_seed(77)
+    hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
+    lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
+    for _ in range(args.warmup):
+        out = validate.evaluate(G, lr, hr, SCALE)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = validate.evaluate(G, lr, hr, SCALE)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({'metric': 'generator inference images/sec (54x54 -> 216x216, x4) incl. device PSNR/SSIM/ERGAS',
+                      'value': round(B * args.steps / dt, 2), 'unit': 'img/s', 'n_gpus': 1, 'steps': args.steps,
+                      'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+                      'dtype': 'f32', 'data': 'synthetic',
+                      'config': {'workload': 'SRADSGAN generator-only x4 inference, batch %d' % B},
+                      'gflop_per_image': 69.19, 'tflops': round(B * args.steps / dt * 69.19 / 1e3, 2),
+                      'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
+
+
 def cpu_baseline_subprocess(iters, timeout_s=240):
     """Runs the CPU leg in a child process (own thread pool, hard wall-clock bound) and returns its dict."""
     import subprocess
@@ -217,6 +247,9 @@ def main():
 
     if args.roofline_only:
         print(json.dumps({'roofline': time_dominant_kernel(device, args.batch)}), flush=True)
+        return
+    if args.workload == 'infer':
+        run_inference(args, device)
         return
     from sradsgan_amd.train_step import TrainStep
     from sradsgan_amd import dp

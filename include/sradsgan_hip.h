@@ -158,6 +158,15 @@ int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, co
                            void* workspace, size_t workspace_bytes, long rows, int c, float slope, int apply_act,
                            void* stream);
 
+/* ---- validation metrics (mfeNew_validate / validate, sradsgan.py:1314-1325; utils/utils.py:923-962):
+ *      images quantised like ToPILImage (mul(255).byte(): truncate + wrap, no clamp), NHWC floats in.
+ * quant_sse: partial uint64 [n][srhip_metric_blocks()][2] = {sum (a_u8-b_u8)^2, sum b_u8} (exact);
+ * ssim_u8 (scikit-image 0.15 compare_ssim, multichannel, 7x7 uniform window): partial double
+ * [n][srhip_metric_blocks()] = sums of the SSIM index over interior pixels and channels (a = test, b = truth). */
+int srhip_metric_blocks(void);
+int srhip_quant_sse(const float* a, const float* b, unsigned long long* partial, int n, long per_image, void* stream);
+int srhip_ssim_u8(const float* a, const float* b, double* partial, int n, int h, int w, int c, void* stream);
+
 /* ---- torch.optim.Adam (sradsgan.py:724-725, step at :858 and :887) over a flat fp32 arena, fused
  *      with the discriminator's weight clip `p.data.clamp_(-c, c)` (:891-892; clip <= 0: none).
  * p,g,m,v: [n] arenas (n % 4 == 0, 16-byte aligned); g is multiplied by grad_scale first (1/world

@@ -1,0 +1,53 @@
+"""Generator inference + validation metrics on the device: the arithmetic of the reference's
+mfeNew_validate / validate loops (SRADSGAN/model/sradsgan.py:1258-1391, 1058-1194) without the per-image
+device->host->PIL->numpy round trip.  Metrics follow the reference bit for bit where it is integer work
+(uint8 quantisation with wrap, MSE, PSNR, ERGAS of utils/utils.py:923-962) and to fp64 roundoff for SSIM
+(scikit-image 0.15 algorithm, parity unpinned: skimage is not vendored by the reference).  LPIPS is not
+reproduced (its AlexNet weights are a download)."""
+import ctypes
+import math
+
+import torch
+
+from . import _hip, ops
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def quantized_metrics(sr, hr, scale):
+    """sr, hr: [N,3,H,W] float tensors on the HIP device (any memory format).  Returns a dict of float64
+    tensors [N]: mse, psnr, ssim, ergas -- per image, exactly what the reference computes after ToPILImage."""
+    ops._require_gpu(sr, 'quantized_metrics')
+    ops._require_gpu(hr, 'quantized_metrics')
+    if sr.shape != hr.shape:
+        raise ValueError('quantized_metrics: shape mismatch %s vs %s' % (tuple(sr.shape), tuple(hr.shape)))
+    sr, hr = ops.nhwc(sr.detach()), ops.nhwc(hr.detach())
+    n, c, h, w = sr.shape
+    lib = _hip.lib()
+    nb = lib.srhip_metric_blocks()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    part = torch.empty(n, nb, 2, device=sr.device, dtype=torch.int64)
+    _hip.check(lib.srhip_quant_sse(_p(sr), _p(hr), _p(part), n, c * h * w, st), 'quant_sse')
+    spart = torch.empty(n, nb, device=sr.device, dtype=torch.float64)
+    _hip.check(lib.srhip_ssim_u8(_p(sr), _p(hr), _p(spart), n, h, w, c, st), 'ssim_u8')
+    sums = part.sum(1).to(torch.float64)
+    count = float(c * h * w)
+    mse = sums[:, 0] / count
+    psnr = torch.where(mse > 0, 10.0 * torch.log10(255.0 ** 2 / mse.clamp_min(1e-300)), torch.full_like(mse, math.inf))
+    mean_gt = sums[:, 1] / count
+    ergas = 100.0 * torch.sqrt(mse / (mean_gt * mean_gt) / c) / scale
+    ssim = spart.sum(1) / float((h - 6) * (w - 6) * c)
+    return dict(mse=mse, psnr=psnr, ssim=ssim, ergas=ergas)
+
+
+@torch.no_grad()
+def evaluate(generator, lr, hr, scale, bicubic=None):
+    """One validation batch: recon = G(lr) (sradsgan.py:1305), metrics of recon vs hr and -- when the
+    bicubic-upsampled input is given -- of bicubic vs hr (:1328-1331).  Returns per-image metric dicts."""
+    recon = generator(lr)
+    out = {'recon': recon, 'sr': quantized_metrics(recon, hr, scale)}
+    if bicubic is not None:
+        out['bicubic'] = quantized_metrics(bicubic, hr, scale)
+    return out

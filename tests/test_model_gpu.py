@@ -245,3 +245,19 @@ def test_generator_inference_psnr_matches_oracle():
         assert abs(O.psnr_u8(tgt, hip_img) - O.psnr_u8(tgt, ref_img)) < 0.05
         assert abs(O.ergas2(tgt, hip_img) - O.ergas2(tgt, ref_img)) < 1e-2
         assert abs(O.ssim_u8(tgt, hip_img) - O.ssim_u8(tgt, ref_img)) < 1e-3
+
+
+def test_device_validation_metrics_match_reference_arithmetic():
+    """sradsgan_amd.validate.quantized_metrics (uint8 wrap quantisation, MSE, PSNR, ERGAS, SSIM on the device)
+    vs the oracle's numpy restatement of sradsgan.py:1314-1325 / utils.py:923-962, incl. out-of-range pixels."""
+    from sradsgan_amd.validate import quantized_metrics
+    g = torch.Generator().manual_seed(9)
+    sr = torch.rand(3, 3, 40, 56, generator=g) * 1.2 - 0.1        # some values < 0 and > 1: exercises the wrap
+    hr = torch.rand(3, 3, 40, 56, generator=g)
+    got = quantized_metrics(sr.to(DEV), hr.to(DEV), 4)
+    for b in range(3):
+        a_img, t_img = O.to_uint8_hwc(sr[b]), O.to_uint8_hwc(hr[b])
+        assert abs(float(got['mse'][b]) - O.mse_u8(t_img, a_img)) < 1e-9
+        assert abs(float(got['psnr'][b]) - O.psnr_u8(t_img, a_img)) < 1e-9
+        assert abs(float(got['ergas'][b]) - O.ergas2(t_img, a_img, 4)) < 1e-9
+        assert abs(float(got['ssim'][b]) - O.ssim_u8(a_img, t_img)) < 1e-9
