@@ -41,10 +41,24 @@ int srhip_abi_version(void);
 /* experiment knobs for kernel tuning (key 0: fast-conv tile configuration, 0 = heuristic) */
 int srhip_debug_set(int key, int value);
 
+/* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *
+ * Replaces the implicit choice torch makes for nn.Conv2d (torch.backends.cudnn.allow_tf32, which the
+ * reference leaves at its default).  Inputs, outputs and accumulation are fp32 in both modes.
+ *   SRHIP_MATH_FP32    every product on v_mfma_f32_32x32x2_f32 (an exact fmaf chain)
+ *   SRHIP_MATH_BF16X3  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16, with
+ *                      ah = bf16(a), al = bf16(a - ah); per-product error <= ~2^-16, measured max error
+ *                      of a 3x3x256 conv vs fp64: 4.5e-6 of max|y| (fp32 chain: 2e-6, TF32: ~5e-4)
+ * Process-wide; applies to the LDS-DMA conv kernels (other shapes always use fp32).            */
+#define SRHIP_MATH_FP32 0
+#define SRHIP_MATH_BF16X3 1
+int srhip_set_conv_math(int mode);
+int srhip_get_conv_math(void);
+
 /* ---- weight packing ------------------------------------------------------------------------ *
  * OIHW parameter -> the GEMM "B" operand the conv kernels read.  mode 0 = fprop operand,
  * mode 1 = dgrad operand.  The internal layout depends only on (cout,cin,kh,kw,mode); the buffer
- * must hold srhip_packed_elems() floats.  Runs once per optimiser step per conv.                */
+ * must hold srhip_packed_elems() floats (for Cin % 16 == 0 shapes: an fp32 copy plus a pre-split
+ * bf16 hi/lo copy for SRHIP_MATH_BF16X3).  Runs once per optimiser step per conv.                */
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode);
 int srhip_pack_weight(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw, int mode,
                       void* stream);

@@ -16,6 +16,8 @@ SIGNATURES = {
     'srhip_last_error': (ctypes.c_char_p, []),
     'srhip_abi_version': (_i, []),
     'srhip_debug_set': (_i, [_i, _i]),
+    'srhip_set_conv_math': (_i, [_i]),
+    'srhip_get_conv_math': (_i, []),
     'srhip_packed_elems': (_sz, [_i] * 5),
     'srhip_pack_entry_bytes': (_i, []),
     'srhip_packed_is_fast': (_i, [_i] * 5),
@@ -58,6 +60,10 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+# arithmetic of the conv contraction unless SRADSGAN_CONV_MATH overrides it (include/sradsgan_hip.h, srhip_set_conv_math)
+DEFAULT_CONV_MATH = 'fp32'
+
+
 def lib():
     """Load (once) and return the shared library; raises HipLibraryError when it is not built."""
     global _lib
@@ -70,6 +76,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
+        mode = os.environ.get('SRADSGAN_CONV_MATH', DEFAULT_CONV_MATH)
+        if mode not in ('fp32', 'bf16x3'):
+            raise HipLibraryError("SRADSGAN_CONV_MATH must be 'fp32' or 'bf16x3', got %r" % mode)
+        handle.srhip_set_conv_math(1 if mode == 'bf16x3' else 0)
         _lib = handle
     return _lib
 

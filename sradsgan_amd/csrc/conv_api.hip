@@ -23,12 +23,12 @@ __global__ void pack_batched_kernel(const PackEntry* __restrict__ tab) {
         const int co = (int)(idx / (khkw * e.cin));
         const int rem = (int)(idx - (long)co * khkw * e.cin);
         const int tap = rem / e.cin, ci = rem - tap * e.cin;
-        e.packed[idx] = e.w[((size_t)co * e.cin + ci) * khkw + tap];
+        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap]);
       } else {
         const int ci = (int)(idx / (khkw * e.cout));
         const int rem = (int)(idx - (long)ci * khkw * e.cout);
         const int tap = rem / e.cout, co = rem - tap * e.cout;
-        e.packed[idx] = e.w[((size_t)co * e.cin + ci) * khkw + tap];
+        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap]);
       }
     }
   } else {
@@ -57,6 +57,7 @@ extern int g_fast_cfg;
 extern int g_wgrad_cfg;
 extern int g_fast_dynlds;
 extern int g_fast_ablate;
+extern int g_conv_math;
 }
 
 extern "C" {
@@ -82,10 +83,17 @@ int srhip_debug_set(int key, int value) {
   return SRHIP_ERR_ARG;
 }
 
+int srhip_set_conv_math(int mode) {
+  SRHIP_REQUIRE(mode == SRHIP_MATH_FP32 || mode == SRHIP_MATH_BF16X3, "set_conv_math: unknown mode");
+  g_conv_math = mode;
+  return SRHIP_OK;
+}
+int srhip_get_conv_math(void) { return g_conv_math; }
+
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode) {
   if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return 0;
   const bool fast = mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw);
-  if (fast) return (size_t)cout * cin * kh * kw;
+  if (fast) return 2 * (size_t)cout * cin * kh * kw;   // fp32 section + split-bf16 section (fast_pack_store)
   const int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
   return (size_t)kh * kw * csrc * legacy_packed_ld(cdst);
 }

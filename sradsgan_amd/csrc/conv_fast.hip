@@ -298,7 +298,21 @@ __device__ inline void lds_dma16(const float* gsrc, unsigned lds_dst_uniform) {
       : "memory");
 }
 
-template <int BM, int BN, int EPI>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// split-bf16 ("bf16x3") product: a*b ~= ah*bh + ah*bl + al*bh with ah = bf16(a), al = bf16(a - ah); the dropped
+// al*bl term and the rounding of al/bl are ~2^-16 relative, accumulation stays fp32 in the MFMA.
+__device__ inline void split_bf16x8(const float4& v0, const float4& v1, bf16x8_t& hi, bf16x8_t& lo) {
+  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+template <int BM, int BN, int EPI, int MATH>
 __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restrict__ src, const float* __restrict__ wt,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ residual,
@@ -395,16 +409,18 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
   // ---- fragment addresses (bytes inside a stage): slot (row, q ^ ((row>>2)&3)), q = ks*2 + khalf ----
   const int wm = wave >> 1, wn = wave & 1;
   const int khalf = lane >> 5, l31 = lane & 31;
+  // MATH 0 (fp32 MFMA 32x32x2, 4 k per read): lane half h takes quads q = h (ks 0) and q = 2 + h (ks 1)
+  // MATH 1 (bf16 MFMA 32x32x16, 8 k per lane):  lane half h takes quads q = 2h and 2h + 1
   int aoff[TM], boff[TN];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int row = wm * WTM + t * 32 + l31;
-    aoff[t] = row * 64 + ((khalf ^ ((row >> 2) & 3)) << 4);
+    aoff[t] = row * 64 + ((((MATH ? 2 : 1) * khalf) ^ ((row >> 2) & 3)) << 4);
   }
 #pragma unroll
   for (int u = 0; u < TN; ++u) {
     const int row = wn * WTN + u * 32 + l31;
-    boff[u] = BM * 64 + row * 64 + ((khalf ^ ((row >> 2) & 3)) << 4);
+    boff[u] = BM * 64 + row * 64 + ((((MATH ? 2 : 1) * khalf) ^ ((row >> 2) & 3)) << 4);
   }
 
   f32x16 acc[TM][TN];
@@ -446,15 +462,15 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < TN; ++u) bf[0][u] = *reinterpret_cast<const float4*>(sb + boff[u]);
 #pragma unroll
-      for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ 32));
+      for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ (MATH ? 16 : 32)));
 #pragma unroll
-      for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ 32));
+      for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ (MATH ? 16 : 32)));
       if (cscale) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
-            const float4 sc = *reinterpret_cast<const float4*>(csrow[t] + c_cc * BK + ks * 8);
+            const float4 sc = *reinterpret_cast<const float4*>(csrow[t] + c_cc * BK + (MATH ? ks * 4 + khalf * 4 : ks * 8));
             af[ks][t].x *= sc.x;
             af[ks][t].y *= sc.y;
             af[ks][t].z *= sc.z;
@@ -465,24 +481,47 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
           ++c_cc;
         }
       }
+      if (MATH == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].x, bf[ks][u].x, acc[t][u]);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].y, bf[ks][u].y, acc[t][u]);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].z, bf[ks][u].z, acc[t][u]);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].w, bf[ks][u].w, acc[t][u]);
+        }
+      } else {
+        bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) split_bf16x8(af[0][t], af[1][t], ah[t], al[t]);
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {   // weights were split when they were packed (fast_pack_store)
+          bh[u] = __builtin_bit_cast(bf16x8_t, bf[0][u]);
+          bl[u] = __builtin_bit_cast(bf16x8_t, bf[1][u]);
+        }
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].x, bf[ks][u].x, acc[t][u]);
+          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].y, bf[ks][u].y, acc[t][u]);
+          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].z, bf[ks][u].z, acc[t][u]);
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].w, bf[ks][u].w, acc[t][u]);
+          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
       }
       stage = stage == 2 ? 0 : stage + 1;
       nstage = nstage == 2 ? 0 : nstage + 1;
@@ -995,12 +1034,12 @@ __global__ void fast_pack_kernel(const float* __restrict__ w, float* __restrict_
     const int co = idx / (khkw * cin);
     const int rem = idx - co * khkw * cin;
     const int tap = rem / cin, ci = rem - tap * cin;
-    packed[idx] = w[((size_t)co * cin + ci) * khkw + tap];
+    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap]);
   } else {
     const int ci = idx / (khkw * cout);
     const int rem = idx - ci * khkw * cout;
     const int tap = rem / cout, co = rem - tap * cout;
-    packed[idx] = w[((size_t)co * cin + ci) * khkw + tap];
+    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap]);
   }
 }
 
@@ -1018,6 +1057,7 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
   return check_launch("fast_pack_weight");
 }
 
+int g_conv_math = 0;     // 0: exact fp32 MFMA; 1: split-bf16 x3 MFMA (srhip_debug_set(4, mode))
 int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_fast(const float* src, const float* wt, const float* bias, const float* residual,
@@ -1053,8 +1093,13 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
 #define SRHIP_LD(BN_, EPI_)                                                                                        \
   do {                                                                                                             \
     const int nbn = cdiv(g.K, BN_);                                                                                \
-    hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src, \
-                       wt, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                        \
+    if (g_conv_math == 1) {                                                                                        \
+      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
+                         src, wt + (g.w_bytes >> 2), bias, residual, rowscale, chanscale, actmask, dst, g, nbm,    \
+                         nbn);                                                                                     \
+    } else                                                                                                         \
+      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 0>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
+                         src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                 \
     return check_launch("fast_conv_dma");                                                                          \
   } while (0)
 #define SRHIP_LDE(BN_)                                                  \

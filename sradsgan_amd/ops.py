@@ -97,6 +97,34 @@ def _grad_slot(p):
 # --------------------------------------------------------------------------------------------- #
 
 
+CONV_MATH_MODES = {'fp32': 0, 'bf16x3': 1}
+
+
+def set_conv_math(mode):
+    """Arithmetic of the conv fprop/dgrad contraction (include/sradsgan_hip.h, srhip_set_conv_math): 'fp32' = fp32
+    MFMA, 'bf16x3' = split-bf16 (three bf16 MFMA products per fp32 product, fp32 accumulate).  Stands where
+    torch.backends.cudnn.allow_tf32 stands for the reference's nn.Conv2d.  Returns the previous mode."""
+    if mode not in CONV_MATH_MODES:
+        raise ValueError('conv math mode must be one of %s' % sorted(CONV_MATH_MODES))
+    lib = _hip.lib()
+    prev = lib.srhip_get_conv_math()
+    _hip.check(lib.srhip_set_conv_math(CONV_MATH_MODES[mode]))
+    return [k for k, v in CONV_MATH_MODES.items() if v == prev][0]
+
+
+def get_conv_math():
+    return [k for k, v in CONV_MATH_MODES.items() if v == _hip.lib().srhip_get_conv_math()][0]
+
+
+@contextlib.contextmanager
+def conv_math(mode):
+    prev = set_conv_math(mode)
+    try:
+        yield
+    finally:
+        set_conv_math(prev)
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError('%s: sradsgan_amd ops run on the MI355X HIP path only (got a %s tensor); '
