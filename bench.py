@@ -33,6 +33,11 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 PER_GPU_BATCH = 32
 SCALE, LR_SIDE = 4, 54
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+# conv arithmetic (include/sradsgan_hip.h srhip_set_conv_math): 'bf16x3' spends three bf16 MFMA products per fp32
+# multiply-accumulate, so the ceiling for ALGORITHMIC flops is a third of the bf16 peak
+MATH_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'f32 MFMA dense'),
+             'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 'bf16 MFMA dense 2500 TFLOP/s / 3 products per fp32 MAC')}
 GF_PER_IMG_ITER = 362.6                # algorithmic GFLOP per image per training iteration (x4)
 
 
@@ -46,6 +51,9 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the compute part from a captured hipGraph (experimental, see DESIGN.md section 6)')
     ap.add_argument('--no-graph', action='store_true', help='(default) launch every kernel eagerly')
+    ap.add_argument('--conv-math', choices=('fp32', 'bf16x3'), default=None,
+                    help="arithmetic of the conv contraction: fp32 MFMA, or split-bf16 x3 MFMA with fp32 accumulate "
+                         "(default: the library default, sradsgan_amd/_hip.py DEFAULT_CONV_MATH)")
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--workload', choices=['train', 'infer'], default='train',
@@ -84,37 +92,52 @@ def build_networks(device, seed):
     return G.to(device), D.to(device), F.to(device)
 
 
-def time_dominant_kernel(device, batch):
-    """HIP-event timing of the dominant kernel on the stream it is launched on: RAB conv1
-    (3x3, 64->256, +bias +LeakyReLU) at the bench shape [batch,64,54,54]."""
+def _time_launches(fn, iters=50):
     import torch
-    from sradsgan_amd import ops
-    x = torch.randn(batch, 64, LR_SIDE, LR_SIDE, device=device).contiguous(memory_format=torch.channels_last)
-    w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=device) * 0.02)
-    b = torch.randn(256, device=device) * 0.01
     for _ in range(5):
-        ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
+        fn()
     torch.cuda.synchronize()
-    iters = 50
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
-        ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
+        fn()
     e.record()
     torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
+    return s.elapsed_time(e) / iters
+
+
+def time_dominant_kernel(device, batch):
+    """HIP-event timing, on the stream they are launched on, of the two kernels that dominate the step at the
+    bench shape [batch,64,54,54] (36 RAB blocks): the conv fprop/dgrad kernel on RAB conv1 (3x3, 64->256, +bias
+    +LeakyReLU) -> 'roofline', and the wgrad kernel on the same conv -> second return value."""
+    import torch
+    from sradsgan_amd import ops
+    math = ops.get_conv_math()
+    peak, peak_name = MATH_PEAK[math]
+    x = torch.randn(batch, 64, LR_SIDE, LR_SIDE, device=device).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(batch, 256, LR_SIDE, LR_SIDE, device=device).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=device) * 0.02)
+    b = torch.randn(256, device=device) * 0.01
     flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9
-    achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None                      # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape)
+    traffic = {}                        # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same mode)
     if batch == PER_GPU_BATCH:
         try:
-            traffic = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            traffic = None
-    return {'bound': 'mfma', 'kernel': 'fast_conv_dma_kernel<128,128,3>: 3x3 64->256 @54x54 +bias +LeakyReLU (RAB conv1)',
-            'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'flops_per_launch': flops,
-            'avg_launch_ms': round(ms, 4), 'dtype_peak': 'f32 MFMA dense'}
+            traffic = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json'))).get(math, {})
+        except (OSError, ValueError):
+            traffic = {}
+    out = []
+    for key, kernel, fn in (
+            ('fprop', 'fast_conv_dma_kernel<128,128,bias+lrelu>: 3x3 64->256 @54x54 fprop (RAB conv1)',
+             lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
+            ('wgrad', 'fast_wgrad_dma_kernel<128,64> + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
+             lambda: ops.conv2d_wgrad_raw(x, dy, (256, 64, 3, 3), 1, 1, True))):
+        ms = _time_launches(fn)
+        achieved = flops / (ms * 1e-3) / 1e12
+        out.append({'bound': 'mfma', 'kernel': kernel, 'conv_math': math, 'achieved': round(achieved, 2),
+                    'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                    'traffic': traffic.get(key), 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4),
+                    'dtype_peak': peak_name})
+    return out[0], out[1]
 
 
 def usable_cores():
@@ -176,7 +199,7 @@ def run_inference(args, device):
     """BASELINE configs[1]: SRADSGAN generator-only x4 inference (mfeNew_validate's G forward, sradsgan.py:1305)
     followed by the device-side validation metrics; batch 16 unless --batch is given."""
     import torch
-    from sradsgan_amd import validate
+    from sradsgan_amd import ops, validate
     B = 16 if args.batch == PER_GPU_BATCH else args.batch
     G, _, _ = build_networks(device, seed=20240)
     G.eval()
@@ -195,7 +218,8 @@ def run_inference(args, device):
                       'value': round(B * args.steps / dt, 2), 'unit': 'img/s', 'n_gpus': 1, 'steps': args.steps,
                       'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
                       'dtype': 'f32', 'data': 'synthetic',
-                      'config': {'workload': 'SRADSGAN generator-only x4 inference, batch %d' % B},
+                      'config': {'workload': 'SRADSGAN generator-only x4 inference, batch %d' % B,
+                                 'conv_math': ops.get_conv_math()},
                       'gflop_per_image': 69.19, 'tflops': round(B * args.steps / dt * 69.19 / 1e3, 2),
                       'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
 
@@ -235,6 +259,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
     from sradsgan_amd import _hip
     _hip.lib()                                               # fail loudly if the extension is missing
+    from sradsgan_amd import ops
+    if args.conv_math:
+        ops.set_conv_math(args.conv_math)
+    conv_math = ops.get_conv_math()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     force_dist = os.environ.get('BENCH_FORCE_DIST') == '1'      # debug: RCCL path with a single rank
@@ -246,7 +274,8 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     if args.roofline_only:
-        print(json.dumps({'roofline': time_dominant_kernel(device, args.batch)}), flush=True)
+        r0, r1 = time_dominant_kernel(device, args.batch)
+        print(json.dumps({'roofline': r0, 'roofline_wgrad': r1}), flush=True)
         return
     if args.workload == 'infer':
         run_inference(args, device)
@@ -309,9 +338,10 @@ def main():
                        'launch': 'hipGraph' if (args.graph and not args.no_graph) else 'eager'},
             'losses_finite': finite, 'last_losses': {k: round(v, 6) for k, v in losses.items()},
             'step_tflops': round(value * GF_PER_IMG_ITER / 1e3, 2),
-            'step_frac_of_f32_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            'step_frac_of_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (MATH_PEAK[conv_math][0] * world), 4),
         }
-        line['roofline'] = time_dominant_kernel(device, B)
+        line['config']['conv_math'] = conv_math
+        line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
         print(json.dumps(line), flush=True)

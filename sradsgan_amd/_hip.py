@@ -61,7 +61,7 @@ class HipLibraryError(RuntimeError):
 
 
 # arithmetic of the conv contraction unless SRADSGAN_CONV_MATH overrides it (include/sradsgan_hip.h, srhip_set_conv_math)
-DEFAULT_CONV_MATH = 'fp32'
+DEFAULT_CONV_MATH = 'bf16x3'
 
 
 def lib():

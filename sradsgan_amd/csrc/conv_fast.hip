@@ -443,85 +443,98 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
   const int T_taps = g.TH * g.TW;
   int c_tap = 0, c_cc = 0;                           // compute-side position in the (cc, tap) loop nest
 
-  if (nk > 0) {
+  auto chunk_sync = [&](int kc) {
+    if (kc + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");   // chunk kc landed; kc+1 may still fly
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // everyone's chunk kc visible; everyone done with chunk kc-1
+    asm volatile("" ::: "memory");
+  };
+  auto read_frags = [&](int stage, float4 (&af)[2][TM], float4 (&bf)[2][TN]) {
+    const char* sb = lds + stage * STAGE_B;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) af[0][t] = *reinterpret_cast<const float4*>(sb + aoff[t]);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bf[0][u] = *reinterpret_cast<const float4*>(sb + boff[u]);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ (MATH ? 16 : 32)));
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ (MATH ? 16 : 32)));
+    if (cscale) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const float4 sc = *reinterpret_cast<const float4*>(csrow[t] + c_cc * BK + (MATH ? ks * 4 + khalf * 4 : ks * 8));
+          af[ks][t].x *= sc.x;
+          af[ks][t].y *= sc.y;
+          af[ks][t].z *= sc.z;
+          af[ks][t].w *= sc.w;
+        }
+      if (++c_tap == T_taps) {
+        c_tap = 0;
+        ++c_cc;
+      }
+    }
+  };
+
+  if (MATH == 0 && nk > 0) {
     issue(0);
     if (nk > 1) issue(1);
     int stage = 0, nstage = 2;                       // nstage: where chunk kc+2 goes
     for (int kc = 0; kc < nk; ++kc) {
-      if (kc + 1 < nk)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");   // chunk kc landed; kc+1 may still fly
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // everyone's chunk kc visible; everyone done with chunk kc-1
-      asm volatile("" ::: "memory");
+      chunk_sync(kc);
       if (kc + 2 < nk) issue(nstage);
-      const char* sb = lds + stage * STAGE_B;
       float4 af[2][TM], bf[2][TN];
+      read_frags(stage, af, bf);
 #pragma unroll
-      for (int t = 0; t < TM; ++t) af[0][t] = *reinterpret_cast<const float4*>(sb + aoff[t]);
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int u = 0; u < TN; ++u) bf[0][u] = *reinterpret_cast<const float4*>(sb + boff[u]);
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
-      for (int t = 0; t < TM; ++t) af[1][t] = *reinterpret_cast<const float4*>(sb + (aoff[t] ^ (MATH ? 16 : 32)));
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].x, bf[ks][u].x, acc[t][u]);
 #pragma unroll
-      for (int u = 0; u < TN; ++u) bf[1][u] = *reinterpret_cast<const float4*>(sb + (boff[u] ^ (MATH ? 16 : 32)));
-      if (cscale) {
+        for (int t = 0; t < TM; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].y, bf[ks][u].y, acc[t][u]);
 #pragma unroll
-          for (int t = 0; t < TM; ++t) {
-            const float4 sc = *reinterpret_cast<const float4*>(csrow[t] + c_cc * BK + (MATH ? ks * 4 + khalf * 4 : ks * 8));
-            af[ks][t].x *= sc.x;
-            af[ks][t].y *= sc.y;
-            af[ks][t].z *= sc.z;
-            af[ks][t].w *= sc.w;
-          }
-        if (++c_tap == T_taps) {
-          c_tap = 0;
-          ++c_cc;
-        }
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].z, bf[ks][u].z, acc[t][u]);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].w, bf[ks][u].w, acc[t][u]);
       }
-      if (MATH == 0) {
+      stage = stage == 2 ? 0 : stage + 1;
+      nstage = nstage == 2 ? 0 : nstage + 1;
+    }
+  }
+  if (MATH == 1 && nk > 0) {
+    // split-bf16: A fragments are split in registers, B was split when it was packed.  (Interleaving the split of
+    // chunk kc+1 with the MFMAs of chunk kc by hand measured the same: the loop is bound by LDS-DMA issue and the
+    // per-chunk barrier, not by VALU/MFMA overlap -- DESIGN.md.)
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0, nstage = 2;
+    for (int kc = 0; kc < nk; ++kc) {
+      chunk_sync(kc);
+      if (kc + 2 < nk) issue(nstage);
+      float4 af[2][TM], bf[2][TN];
+      read_frags(stage, af, bf);
+      bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+      for (int t = 0; t < TM; ++t) split_bf16x8(af[0][t], af[1][t], ah[t], al[t]);
 #pragma unroll
-          for (int t = 0; t < TM; ++t)
+      for (int u = 0; u < TN; ++u) {   // weights were split when they were packed (fast_pack_store)
+        bh[u] = __builtin_bit_cast(bf16x8_t, bf[0][u]);
+        bl[u] = __builtin_bit_cast(bf16x8_t, bf[1][u]);
+      }
 #pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].x, bf[ks][u].x, acc[t][u]);
-#pragma unroll
-          for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].y, bf[ks][u].y, acc[t][u]);
-#pragma unroll
-          for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].z, bf[ks][u].z, acc[t][u]);
-#pragma unroll
-          for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(af[ks][t].w, bf[ks][u].w, acc[t][u]);
-        }
-      } else {
-        bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int t = 0; t < TM; ++t) split_bf16x8(af[0][t], af[1][t], ah[t], al[t]);
-#pragma unroll
-        for (int u = 0; u < TN; ++u) {   // weights were split when they were packed (fast_pack_store)
-          bh[u] = __builtin_bit_cast(bf16x8_t, bf[0][u]);
-          bl[u] = __builtin_bit_cast(bf16x8_t, bf[1][u]);
-        }
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+      for (int i = 0; i < 3 * TM * TN; ++i) {          // product order al*bh, ah*bl, ah*bh; accumulator chains interleaved
+        const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
       }
       stage = stage == 2 ? 0 : stage + 1;
       nstage = nstage == 2 ? 0 : nstage + 1;
@@ -814,7 +827,9 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict
 // ---- wgrad, LDS-DMA variant: same ring / counted-vmcnt structure as fast_conv_dma_kernel.  Both
 // operands are pixel-major, so a stage is simply [16 pixels][BM] + [16 pixels][BN] floats, written
 // lane-linear by the DMA and read back as conflict-free ds_read_b32 (consecutive dwords) -- no swizzle.
-template <int BM, int BN, int WM, int WN, int WBK>
+// MATH 1 (SRHIP_MATH_BF16X3): a lane gathers its 8 consecutive pixels of one channel with 8 ds_read_b32 (still
+// consecutive dwords across lanes), splits them into bf16 hi/lo and issues three 32x32x16 MFMAs per tile pair.
+template <int BM, int BN, int WM, int WN, int WBK, int MATH>
 __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ partial,
                                                               float* __restrict__ bias_partial, WgradGeom g) {
@@ -932,17 +947,53 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
       if (kc + 2 < nk) issue(nstage);
       const float* a = reinterpret_cast<const float*>(lds + stage * STAGE_B) + khalf * BM + wm * WTM + l31;
       const float* b = reinterpret_cast<const float*>(lds + stage * STAGE_B) + WBK * BM + khalf * BN + wn * WTN + l31;
+      if (MATH == 0) {
 #pragma unroll
-      for (int kk = 0; kk < WBK / 2; ++kk) {
-        float av[TM], bv[TN];
+        for (int kk = 0; kk < WBK / 2; ++kk) {
+          float av[TM], bv[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * BM + t * 32];
+          for (int t = 0; t < TM; ++t) av[t] = a[kk * 2 * BM + t * 32];
 #pragma unroll
-        for (int u = 0; u < TN; ++u) bv[u] = b[kk * 2 * BN + u * 32];
+          for (int u = 0; u < TN; ++u) bv[u] = b[kk * 2 * BN + u * 32];
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
+          for (int t = 0; t < TM; ++t)
 #pragma unroll
-          for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(av[t], bv[u], acc[t][u]);
+            for (int u = 0; u < TN; ++u) acc[t][u] = mfma32f(av[t], bv[u], acc[t][u]);
+        }
+      } else {
+        // pixel rows khalf*8 .. khalf*8+7 of each 16-pixel step (a/b above start at row khalf: rebase to khalf*8)
+        const float* a8 = a + 7 * khalf * BM;
+        const float* b8 = b + 7 * khalf * BN;
+#pragma unroll
+        for (int ks = 0; ks < WBK / 16; ++ks) {
+          bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a8[(ks * 16 + j) * BM + t * 32];
+            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ah[t], al[t]);
+          }
+#pragma unroll
+          for (int u = 0; u < TN; ++u) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = b8[(ks * 16 + j) * BN + u * 32];
+            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bh[u], bl[u]);
+          }
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+        }
       }
       if (want_bias) {
         const float* col = reinterpret_cast<const float*>(lds + stage * STAGE_B) + tid;
@@ -1268,11 +1319,14 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
 #define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                            \
-    if (!xrow && !xchan && g_wgrad_cfg < 10 && p.bk == 32)                                                        \
-      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 32>), dim3(blocks), dim3(256), 0, st, x, dy, \
+    if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 1)                                                  \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16, 1>), dim3(blocks), dim3(256), 0, st, x, dy, \
+                         partial, db ? bias_partial : nullptr, g);                                               \
+    else if (!xrow && !xchan && g_wgrad_cfg < 10 && p.bk == 32)                                                        \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 32, 0>), dim3(blocks), dim3(256), 0, st, x, dy, \
                          partial, db ? bias_partial : nullptr, g);                                               \
     else if (!xrow && !xchan && g_wgrad_cfg < 10)                                                                 \
-      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16>), dim3(blocks), dim3(256), 0, st, x, dy, \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16, 0>), dim3(blocks), dim3(256), 0, st, x, dy, \
                          partial, db ? bias_partial : nullptr, g);                                               \
     else                                                                                                          \
       hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \

@@ -188,12 +188,14 @@ def test_batch_norm_lrelu_fwd_bwd_double_bwd(shape):
     assert int(got[7]) == int(ref[7]) == 1
 
 
-@pytest.fixture
-def force_dma():
-    """The LDS-DMA conv kernels are normally chosen only for >= 512 tiles; force them for small test shapes."""
-    from sradsgan_amd import _hip
+@pytest.fixture(params=['fp32', 'bf16x3'])
+def force_dma(request):
+    """The LDS-DMA conv kernels are normally chosen only for >= 512 tiles; force them for small test shapes,
+    once per arithmetic mode (fp32 MFMA and split-bf16 MFMA, include/sradsgan_hip.h srhip_set_conv_math)."""
+    from sradsgan_amd import _hip, ops
     _hip.lib().srhip_debug_set(0, -1)
-    yield
+    with ops.conv_math(request.param):
+        yield request.param
     _hip.lib().srhip_debug_set(0, 0)
 
 
@@ -221,3 +223,35 @@ def test_dma_conv_fused_epilogues(force_dma):
     assert _rel(got, ref) < TOL
     test_conv_operand_scaling()
     test_conv_residual_epilogue()
+
+
+@pytest.mark.parametrize('mode,tol', [('fp32', 5e-6), ('bf16x3', 1.5e-5)])
+def test_conv_math_modes_against_fp64(mode, tol):
+    """Both arithmetic modes of the conv contraction against an fp64 reference at a size where the LDS-DMA
+    kernels are the ones chosen (RAB conv at 54x54, batch 8): fprop, dgrad and wgrad.  The split-bf16 mode must
+    stay within a few fp32 ulps-of-max of the exact chain (measured 4.5e-6 vs 2e-6; TF32, the reference's own
+    default on its GPUs, is ~5e-4)."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, h = 8, 256, 256, 54
+    x = torch.randn(n, cin, h, h, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, h, h, generator=g)
+    xd, wd, dyd = x.double(), wt.double(), dy.double()
+    ref_y = F.leaky_relu(F.conv2d(xd, wd, b.double(), padding=1), 0.2)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wd, dyd, padding=1)
+    ref_dw = torch.nn.grad.conv2d_weight(xd, wt.shape, dyd, padding=1)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    dyg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+    wg = torch.nn.Parameter(wt.to(dev))
+    with ops.conv_math(mode):
+        assert ops.get_conv_math() == mode
+        y = ops.conv2d_fwd_raw(xg, wg, b.to(dev), 1, 1, 0.2)
+        dx = ops.conv2d_dgrad_raw(dyg, wg, tuple(x.shape), 1, 1)
+        dw, db = ops.conv2d_wgrad_raw(xg, dyg, tuple(wt.shape), 1, 1, True)
+    assert _rel(y, ref_y) < tol
+    assert _rel(dx, ref_dx) < tol
+    assert _rel(dw, ref_dw) < tol
+    assert _rel(db, dyd.sum((0, 2, 3))) < 5e-6
