@@ -181,7 +181,8 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
       if (BN % RPP == 0 || lrow + RPP * j < BN) *reinterpret_cast<float4*>(b + RPP * j * LS) = rb[j];
   };
 
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int khalf = lane >> 5, l31 = lane & 31;
 
@@ -312,6 +313,44 @@ __device__ inline void split_bf16x8(const float4& v0, const float4& v1, bf16x8_t
   }
 }
 
+// epilogue of one float4 of output (4 consecutive channels n.. of destination pixel dpix)
+__device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, const FastGeom& g,
+                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                       const float* __restrict__ rowscale, const float* __restrict__ actmask,
+                                       float* __restrict__ dst) {
+  if (flags & SRHIP_EPI_ROWSCALE) {
+    const float rsc = rowscale[dpix];
+    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+  }
+  if (flags & SRHIP_EPI_BIAS) {
+    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+  }
+  if (flags & SRHIP_EPI_LRELU) {
+    v.x = v.x > 0.f ? v.x : v.x * g.slope;
+    v.y = v.y > 0.f ? v.y : v.y * g.slope;
+    v.z = v.z > 0.f ? v.z : v.z * g.slope;
+    v.w = v.w > 0.f ? v.w : v.w * g.slope;
+  }
+  if (flags & SRHIP_EPI_ACTMASK) {
+    const float4 a4 = *reinterpret_cast<const float4*>(actmask + dpix * g.ldd + n);
+    v.x = a4.x > 0.f ? v.x : v.x * g.slope;
+    v.y = a4.y > 0.f ? v.y : v.y * g.slope;
+    v.z = a4.z > 0.f ? v.z : v.z * g.slope;
+    v.w = a4.w > 0.f ? v.w : v.w * g.slope;
+  }
+  if (flags & SRHIP_EPI_RESIDUAL) {
+    const float4 r4 = *reinterpret_cast<const float4*>(residual + dpix * g.ldr + n);
+    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+  }
+  float4* o = reinterpret_cast<float4*>(dst + dpix * g.ldd + n);
+  if (g.accumulate) {
+    const float4 p4 = *o;
+    v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+  }
+  *o = v;
+}
+
 template <int BM, int BN, int EPI, int MATH>
 __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restrict__ src, const float* __restrict__ wt,
                                                              const float* __restrict__ bias,
@@ -328,7 +367,8 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
   constexpr int STAGE_B = (BM + BN) * 64;              // bytes per stage (64 B per row)
   __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE_B];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps per-wave control flow on the scalar unit
   const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
   const int tile_n = tile % nblk_n, tile_m = tile / nblk_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -573,39 +613,247 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
         const int ow = rem - oh * g.OW;
         dpix = ((size_t)nimg * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
       }
-      if (flags & SRHIP_EPI_ROWSCALE) {
-        const float rsc = rowscale[dpix];
-        v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
-      }
-      if (flags & SRHIP_EPI_BIAS) {
-        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
-        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      }
-      if (flags & SRHIP_EPI_LRELU) {
-        v.x = v.x > 0.f ? v.x : v.x * g.slope;
-        v.y = v.y > 0.f ? v.y : v.y * g.slope;
-        v.z = v.z > 0.f ? v.z : v.z * g.slope;
-        v.w = v.w > 0.f ? v.w : v.w * g.slope;
-      }
-      if (flags & SRHIP_EPI_ACTMASK) {
-        const float4 a4 = *reinterpret_cast<const float4*>(actmask + dpix * g.ldd + n);
-        v.x = a4.x > 0.f ? v.x : v.x * g.slope;
-        v.y = a4.y > 0.f ? v.y : v.y * g.slope;
-        v.z = a4.z > 0.f ? v.z : v.z * g.slope;
-        v.w = a4.w > 0.f ? v.w : v.w * g.slope;
-      }
-      if (flags & SRHIP_EPI_RESIDUAL) {
-        const float4 r4 = *reinterpret_cast<const float4*>(residual + dpix * g.ldr + n);
-        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-      }
-      float4* o = reinterpret_cast<float4*>(dst + dpix * g.ldd + n);
-      if (g.accumulate) {
-        const float4 p4 = *o;
-        v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
-      }
-      *o = v;
+      epi_apply_store(v, dpix, n, flags, g, bias, residual, rowscale, actmask, dst);
     }
     if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the region is rewritten
+  }
+}
+
+// ================================================================================================ //
+// fprop / dgrad of stride-1 3x3 convolutions in split-bf16 arithmetic: "patch" kernel.
+// In fast_conv_dma_kernel every tap re-fetches its own 128-row A tile from L2; at the bf16 MFMA rate the kernel
+// is then bound by LDS-DMA issue (4 x 1 KiB per wave per 12 MFMAs), not by the matrix pipe (ablation in
+// DESIGN.md).  Here a block owns a PH x PW patch of output pixels (PH*PW <= 128) and keeps the (PH+2) x (PW+2)
+// input halo of one 16-channel chunk in LDS; all nine taps read their A fragments from that one patch at shifted
+// row addresses, so A traffic drops ~6x and only the B (weight) tile is streamed per tap.  Each wave converts the
+// patch pieces it fetched itself from fp32 to the split hi|lo layout IN PLACE (once per element, instead of once
+// per fragment read in every tap and wave), so fragments of both operands come out of LDS ready for the MFMA.
+//   LDS: 2 patch buffers (chunk cc / cc+1) + a 3-stage ring of B tiles (one tap each), one barrier per tap.
+//   Results are bit-identical to fast_conv_dma_kernel<.., MATH 1>: same split, same product and chunk order.
+// ================================================================================================ //
+struct PatchGeom {
+  int PH, PW, tiles_h, tiles_w;    // output patch and patches per image
+  int PWP, PR, npieces;            // patch width incl. halo, patch rows, 16-row DMA pieces
+  int lo_h, lo_w;                  // source pixel of patch row (0,0) = (oh0 + lo_h, ow0 + lo_w)
+};
+
+template <int N>
+__device__ inline void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int I>
+struct IC {
+  static constexpr int value = I;
+};
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ residual,
+                                                          const float* __restrict__ actmask, float* __restrict__ dst,
+                                                          FastGeom g, PatchGeom pg, int nblk_m, int nblk_n) {
+  constexpr int NW = 4, BK = 16;
+  constexpr int WTM = 64, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int BPW = BN / 64;                      // B DMA pieces per wave per tap
+  constexpr int MAXP = 3;                           // A patch pieces per wave: 12 pieces = 192 rows per patch
+  constexpr int PATCH_B = 12 * 1024;
+  constexpr int BSTAGE_B = BN * 64;
+  constexpr int EPI_B = NW * 32 * WTN * 4;
+  constexpr int LDS_B = 2 * PATCH_B + 3 * BSTAGE_B > EPI_B ? 2 * PATCH_B + 3 * BSTAGE_B : EPI_B;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
+  const int tile_n = tile % nblk_n, pid = tile / nblk_n;
+  const int n0 = tile_n * BN;
+  const int tpi = pg.tiles_h * pg.tiles_w;
+  const int img = pid / tpi;
+  const int prem = pid - img * tpi;
+  const int ty = prem / pg.tiles_w, tx = prem - ty * pg.tiles_w;
+  const int oh0 = ty * pg.PH, ow0 = tx * pg.PW;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  // ---- A patch DMA: piece p = k*NW + wave covers patch rows 16p .. 16p+15; this lane feeds (row, slot lane&3).
+  // Every wave always moves MAXP pieces (rows past the patch come from the zero block and are never read), so the
+  // number of DMAs in flight is the same compile-time constant for all waves.
+  const int swz = (lane >> 4) & 3;                  // ((16p + lane/4) >> 2) & 3
+  const int aq = (lane & 3) ^ swz;                  // global 16-byte quad held by this lane's slot
+  int abase[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int row = (k * NW + wave) * 16 + (lane >> 2);
+    abase[k] = -1;
+    if (row < pg.PR) {
+      const int pi = row / pg.PWP, pj = row - pi * pg.PWP;
+      const int sh = oh0 + pg.lo_h + pi, sw = ow0 + pg.lo_w + pj;
+      if (sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws) abase[k] = ((img * g.Hs + sh) * g.Ws + sw) * g.lds + aq * 4;
+    }
+  }
+  int bbase[BPW];
+  bool bval[BPW];
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) {
+    const int n = n0 + wave * 16 * BPW + 16 * j + (lane >> 2);
+    bval[j] = n < g.K;
+    bbase[j] = n * g.ldw + aq * 4;                  // ((row >> 2) & 3) == swz here too (16-row pieces)
+  }
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * PATCH_B + wave * BPW * 1024);
+
+  const int CC = g.C / BK;
+  int wtap[9];                                      // packed-weight column of tap t (scalar registers)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
+
+  auto issue_a = [&](int buf, int k, int cc) {      // one 1 KiB piece of the patch of chunk cc
+    const float* p = abase[k] >= 0 ? src + (long)(abase[k] + cc * BK) : g_zero16;
+    lds_dma16(p, a_dst + buf * PATCH_B + k * (NW * 1024));
+  };
+  auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
+    const int wk = wtap[tap] + cc * BK;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
+      lds_dma16(p, b_dst + stage * BSTAGE_B + j * 1024);
+    }
+  };
+  // fp32 -> split bf16 in place for one piece this wave fetched: lanes 2i, 2i+1 hold the two quads (8 consecutive
+  // channels) of a half row; the lane with the even quad keeps the 8 hi halves, the odd one the 8 lo halves
+  auto convert_piece = [&](int buf, int k) {
+    float4* slot = reinterpret_cast<float4*>(lds + buf * PATCH_B + (k * NW + wave) * 1024 + lane * 16);
+    const float4 own = *slot;
+    float4 oth;
+    oth.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.x), 0xB1, 0xF, 0xF, true));
+    oth.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.y), 0xB1, 0xF, 0xF, true));
+    oth.z = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.z), 0xB1, 0xF, 0xF, true));
+    oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
+    const bool odd = aq & 1;                        // this lane's quad is the second half of the 8-group
+    bf16x8_t hi, lo;
+    split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
+    *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
+  };
+
+  // ---- fragment addressing: everything but the patch-buffer parity is fixed for the whole kernel ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  int aoff[9][TM];                                  // byte offset (buffer 0) of this lane's hi quad for tap t
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * WTM + t * 32 + l31;
+    const int orow = r / pg.PW, ocol = r - orow * pg.PW;
+    const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;   // dead rows (r >= PH*PW) read pixel 0, never stored
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int a_th = (g.dh0 + (tap / 3) * g.dhs) - pg.lo_h, a_tw = (g.dw0 + (tap % 3) * g.dws) - pg.lo_w;
+      const int pr = arow + a_th * pg.PWP + a_tw;
+      aoff[tap][t] = pr * 64 + (((2 * khalf) ^ ((pr >> 2) & 3)) << 4);
+    }
+  }
+  int boff[TN];
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int row = wn * WTN + u * 32 + l31;
+    boff[u] = 2 * PATCH_B + row * 64 + (((2 * khalf) ^ ((row >> 2) & 3)) << 4);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  // One tap of one chunk.  TAP and LAST (= this is the final chunk) are compile-time, so which DMAs are issued,
+  // which piece is converted, the ring slots and the vmcnt count are all immediates: the loop body is a straight
+  // line of [wait, barrier, <= 3 DMAs, 8 ds_read_b128, 12 MFMAs].
+  //   DMA order inside a tap: the A piece (taps 0..2, for chunk cc+1), then the B tile of tap+2.
+  //   At tap t the B tile of t (issued at t-2) must have landed; issued after it: the A piece of tap t-1 (if any)
+  //   and the B tile of t+1 (if any) -> that many DMAs may stay in flight.
+  auto do_tap = [&](auto tapc, auto lastc, int cc) {
+    constexpr int TAP = decltype(tapc)::value;
+    constexpr bool LAST = decltype(lastc)::value != 0;
+    constexpr int NEWER = ((LAST && TAP == 8) ? 0 : BPW) + ((!LAST && TAP >= 1 && TAP <= MAXP) ? 1 : 0);
+    wait_vmcnt<NEWER>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's in-place conversions are in LDS
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int pbuf = cc & 1;
+    if (!LAST && TAP < MAXP) issue_a(pbuf ^ 1, TAP, cc + 1);
+    if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
+    else if (!LAST) issue_b((TAP + 2) % 3, TAP + 2 - 9, cc + 1);
+    if (!LAST && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);   // landed: it is older than B tile TAP
+    const char* pb = lds + pbuf * PATCH_B;
+    const char* sb = lds + (TAP % 3) * BSTAGE_B;
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      ah[t] = *reinterpret_cast<const bf16x8_t*>(pb + aoff[TAP][t]);
+      al[t] = *reinterpret_cast<const bf16x8_t*>(pb + (aoff[TAP][t] ^ 16));
+    }
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boff[u]);
+      bl[u] = *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * TM * TN; ++i) {          // same product order as fast_conv_dma_kernel
+      const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+    }
+  };
+  auto do_chunk = [&](auto lastc, int cc) {
+    do_tap(IC<0>(), lastc, cc);
+    do_tap(IC<1>(), lastc, cc);
+    do_tap(IC<2>(), lastc, cc);
+    do_tap(IC<3>(), lastc, cc);
+    do_tap(IC<4>(), lastc, cc);
+    do_tap(IC<5>(), lastc, cc);
+    do_tap(IC<6>(), lastc, cc);
+    do_tap(IC<7>(), lastc, cc);
+    do_tap(IC<8>(), lastc, cc);
+  };
+
+  // prologue: whole patch of chunk 0, B tiles of taps 0 and 1; convert the patch once B tile 0 (issued after it) is in
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
+  issue_b(0, 0, 0);
+  issue_b(1, 1, 0);
+  wait_vmcnt<BPW>();
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+  for (int cc = 0; cc + 1 < CC; ++cc) do_chunk(IC<0>(), cc);
+  do_chunk(IC<1>(), CC - 1);
+
+  // ---- epilogue (as fast_conv_dma_kernel): accumulators -> wave-private LDS -> row-contiguous float4s ----
+  const int flags = EPI >= 0 ? EPI : g.flags;
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(lds) + wave * (32 * WTN);
+  constexpr int QPRW = WTN / 4;
+  constexpr int NRD = 32 * QPRW / 64;
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + u * 32 + l31] = acc[t][u][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      const int idx = i * 64 + lane;
+      const int row = idx / QPRW, cq = idx - row * QPRW;
+      const float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+      const int r = wm * WTM + t * 32 + row;
+      const int orow = r / pg.PW, ocol = r - orow * pg.PW;
+      const int oh = oh0 + orow, ow = ow0 + ocol;
+      const int n = n0 + wn * WTN + cq * 4;
+      if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
+      const size_t dpix = ((size_t)img * g.Hd + oh) * g.Wd + ow;
+      epi_apply_store(v, dpix, n, flags, g, bias, residual, nullptr, actmask, dst);
+    }
+    if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -752,7 +1000,8 @@ __global__ __launch_bounds__(256) void fast_wgrad_kernel(const float* __restrict
     for (int j = 0; j < BV; ++j) *reinterpret_cast<float4*>(b + (b_row0 + j * (256 / BQ)) * LDB + b_c * 4) = rb[j];
   };
 
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int khalf = lane >> 5, l31 = lane & 31;
   f32x16 acc[TM][TN];
@@ -841,7 +1090,8 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
   constexpr int STAGE_B = (BM + BN) * WBK * 4;
   __shared__ __attribute__((aligned(1024))) char lds[3 * STAGE_B];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps per-wave control flow on the scalar unit
   const int ntn = (g.Ktot + BN - 1) / BN;
   const int ntm = (g.K + BM - 1) / BM;
   // XCD-aware order: every tile (tile_m, tile_n) of one pixel split runs on the same XCD (blocks b, b+8,
@@ -1123,6 +1373,35 @@ static int launch_fast(const float* src, const float* wt, const float* bias, con
 // experiment knob (srhip_debug_set(0, cfg)): 0 = heuristic below
 int g_fast_cfg = 0;
 
+// Patch shape for conv_patch_kernel: PH x PW output pixels per block (<= 128), halo patch <= 192 rows = 12 DMA pieces; picks the
+// shape that wastes the fewest of the 128 GEMM rows over the whole image (halo patch <= 192 rows = 12 DMA pieces).  Only stride-1 3x3 geometries.
+static bool plan_patch(const FastGeom& g, PatchGeom* pg) {
+  if (g.TH != 3 || g.TW != 3 || g.ss != 1 || g.dsd != 1 || g.ph != 0 || g.pw != 0) return false;
+  if ((g.dhs != 1 && g.dhs != -1) || (g.dws != 1 && g.dws != -1)) return false;
+  if (g.Hd != g.OH || g.Wd != g.OW) return false;
+  double best = 0.0;
+  for (int pw = 4; pw <= 64 && pw <= g.OW + 3; ++pw) {
+    int ph = 128 / pw;
+    if (ph > g.OH) ph = g.OH;
+    if (ph < 1 || (ph + 2) * (pw + 2) > 192) continue;
+    const long tiles = (long)cdiv(g.OH, ph) * cdiv(g.OW, pw);
+    const double eff = (double)g.OH * g.OW / ((double)tiles * 128.0);
+    if (eff > best + 1e-9) {
+      best = eff;
+      pg->PH = ph; pg->PW = pw;
+    }
+  }
+  if (best < 0.70) return false;
+  pg->tiles_h = cdiv(g.OH, pg->PH);
+  pg->tiles_w = cdiv(g.OW, pg->PW);
+  pg->PWP = pg->PW + 2;
+  pg->PR = (pg->PH + 2) * pg->PWP;
+  pg->npieces = cdiv(pg->PR, 16);
+  pg->lo_h = g.dhs > 0 ? g.dh0 : g.dh0 + 2 * g.dhs;
+  pg->lo_w = g.dws > 0 ? g.dw0 : g.dw0 + 2 * g.dws;
+  return true;
+}
+
 static int run_fast(const float* src, const float* wt, const float* bias, const float* residual,
                     const float* rowscale, const float* chanscale, const float* actmask, float* dst, const FastGeom& g,
                     hipStream_t st) {
@@ -1134,6 +1413,38 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   const int eflags = g.flags & 0xff;      // bits 0x100/0x200: ablations (reg kernel), 0x400: s_setprio experiment
   const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+  // stride-1 3x3 in split-bf16: the patch kernel (g_fast_cfg 21 turns it off, -2 forces it at any size)
+  if (g_conv_math == 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+      !(eflags & (SRHIP_EPI_CHANSCALE | SRHIP_EPI_ROWSCALE)) && !g.accumulate) {
+    PatchGeom pg;
+    if (plan_patch(g, &pg)) {
+      const int nbm = g.N * pg.tiles_h * pg.tiles_w;
+      const bool wide = g.K >= 128;
+      const int nbn = cdiv(g.K, wide ? 128 : 64);
+      if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
+        const float* wsplit = wt + (g.w_bytes >> 2);
+#define SRHIP_LP(BN_, EPI_)                                                                                         \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((conv_patch_kernel<BN_, EPI_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias,       \
+                       residual, actmask, dst, g, pg, nbm, nbn);                                                   \
+    return check_launch("conv_patch");                                                                              \
+  } while (0)
+#define SRHIP_LPE(BN_)                                                  \
+  do {                                                                  \
+    if (eflags == 0) SRHIP_LP(BN_, 0);                                  \
+    if (eflags == SRHIP_EPI_BIAS) SRHIP_LP(BN_, 1);                     \
+    if (eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_LP(BN_, 3); \
+    if (eflags == SRHIP_EPI_ACTMASK) SRHIP_LP(BN_, 32);                 \
+    if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LP(BN_, 4);                 \
+    SRHIP_LP(BN_, -1);                                                  \
+  } while (0)
+        if (wide) SRHIP_LPE(128);
+        SRHIP_LPE(64);
+#undef SRHIP_LPE
+#undef SRHIP_LP
+      }
+    }
+  }
   if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       (!(eflags & SRHIP_EPI_CHANSCALE) || ((uintptr_t)chanscale & 15) == 0)) {
     const int nbm = cdiv(g.M, 128);
