@@ -57,7 +57,22 @@ __device__ inline int xcd_tile(int b, int nblk) {
 // ================================================================================================ //
 // fprop / dgrad
 // ================================================================================================ //
-template <int BM, int BN, int WM, int WN, int BK>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// split-bf16 ("bf16x3") product: a*b ~= ah*bh + ah*bl + al*bh with ah = bf16(a), al = bf16(a - ah); the dropped
+// al*bl term and the rounding of al/bl are ~2^-16 relative, accumulation stays fp32 in the MFMA.
+__device__ inline void split_bf16x8(const float4& v0, const float4& v1, bf16x8_t& hi, bf16x8_t& lo) {
+  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+// MATH 1 (BK 16 only): split-bf16 products, B read from the pre-split section of the packed weights
+template <int BM, int BN, int WM, int WN, int BK, int MATH = 0>
 __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __restrict__ src,
                                                                  const float* __restrict__ wt,
                                                                  const float* __restrict__ bias,
@@ -202,6 +217,27 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
     for (int kc = 0; kc < nk; ++kc) {
       const int stage = abl_noload ? 0 : (kc & 1);
       if (kc + 1 < nk && !abl_noload) load_tiles();
+      if (MATH == 1) {
+        const float* a = lds + stage * STAGE + (wm * WTM + l31) * LS + khalf * 8;
+        const float* b = lds + stage * STAGE + BM * LS + (wn * WTN + l31) * LS + khalf * 8;
+        bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          split_bf16x8(*reinterpret_cast<const float4*>(a + t * 32 * LS), *reinterpret_cast<const float4*>(a + t * 32 * LS + 4), ah[t], al[t]);
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+          bh[u] = *reinterpret_cast<const bf16x8_t*>(b + u * 32 * LS);
+          bl[u] = *reinterpret_cast<const bf16x8_t*>(b + u * 32 * LS + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * TM * TN; ++i) {
+          const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+        }
+        if (kc + 1 < nk && !abl_noload) store_tiles(stage ^ 1);
+        if (!abl_nobar) __syncthreads();
+        continue;
+      }
       const float* a = lds + stage * STAGE + (wm * WTM + l31) * LS + khalf * 4;
       const float* b = lds + stage * STAGE + BM * LS + (wn * WTN + l31) * LS + khalf * 4;
       float4 af[2][TM], bf[2][TN];
@@ -297,20 +333,6 @@ __device__ inline void lds_dma16(const float* gsrc, unsigned lds_dst_uniform) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst_uniform)
       : "memory");
-}
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-// split-bf16 ("bf16x3") product: a*b ~= ah*bh + ah*bl + al*bh with ah = bf16(a), al = bf16(a - ah); the dropped
-// al*bl term and the rounding of al/bl are ~2^-16 relative, accumulation stays fp32 in the MFMA.
-__device__ inline void split_bf16x8(const float4& v0, const float4& v1, bf16x8_t& hi, bf16x8_t& lo) {
-  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(v[j] - (float)h);
-  }
 }
 
 // epilogue of one float4 of output (4 consecutive channels n.. of destination pixel dpix)
@@ -1408,6 +1430,12 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   if (g.M <= 0) return SRHIP_OK;
 #define SRHIP_LF(BM_, BN_, WM_, WN_, BK_) \
   return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
+  if (g.K <= 32 && g_conv_math == 1 && g_fast_cfg != 20 && !(g.flags & (SRHIP_EPI_CHANSCALE | 0x300))) {
+    const int nbm = cdiv(g.M, 128), nbn = cdiv(g.K, 32);
+    hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,
+                       wt + (g.w_bytes >> 2), bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
+    return check_launch("fast_conv");
+  }
   if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
   // LDS-DMA kernels (g_fast_cfg 20 forces them off): no A-operand scaling, ablation flags or accumulate variants needed
   const int eflags = g.flags & 0xff;      // bits 0x100/0x200: ablations (reg kernel), 0x400: s_setprio experiment
@@ -1580,6 +1608,9 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
     if (cout % 256 == 0 && ktot % 64 == 0) { p.bm = 256; p.bn = 64; }
     else if (cout == 64 && ktot % 256 == 0) { p.bm = 64; p.bn = 256; }
   }
+  // split-bf16 wgrad is VALU-issue bound (every wave splits the fragments it reads): where Ktot only tiles by 64
+  // (Cin = 64), a 256 x 64 tile doubles the MFMAs per split fragment (measured -10 % on 64->256 convs)
+  if (g_conv_math == 1 && g_wgrad_cfg == 0 && p.bn == 64 && cout % 256 == 0) p.bm = 256;
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
   const int nchunks = cdiv(P, p.bk);
   long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
@@ -1630,7 +1661,7 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
 #define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                            \
-    if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 1)                                                  \
+    if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 1)                                           \
       hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16, 1>), dim3(blocks), dim3(256), 0, st, x, dy, \
                          partial, db ? bias_partial : nullptr, g);                                               \
     else if (!xrow && !xchan && g_wgrad_cfg < 10 && p.bk == 32)                                                        \
