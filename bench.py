@@ -126,10 +126,11 @@ def time_dominant_kernel(device, batch):
         except (OSError, ValueError):
             traffic = {}
     out = []
+    kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_kernel<128,bias+lrelu>'}[math]
+    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'fast_wgrad_dma_kernel<256,64,bf16x3>'}[math]
     for key, kernel, fn in (
-            ('fprop', 'fast_conv_dma_kernel<128,128,bias+lrelu>: 3x3 64->256 @54x54 fprop (RAB conv1)',
-             lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
-            ('wgrad', 'fast_wgrad_dma_kernel<128,64> + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
+            ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
+            ('wgrad', kw + ' + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
              lambda: ops.conv2d_wgrad_raw(x, dy, (256, 64, 3, 3), 1, 1, True))):
         ms = _time_launches(fn)
         achieved = flops / (ms * 1e-3) / 1e12

@@ -1477,9 +1477,12 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       (!(eflags & SRHIP_EPI_CHANSCALE) || ((uintptr_t)chanscale & 15) == 0)) {
     const int nbm = cdiv(g.M, 128);
     const bool force = g_fast_cfg == -1;                 // tests: take the DMA kernels at any problem size
-    const bool wide = g.K >= 128 && ((long)nbm * cdiv(g.K, 128) >= 512 || force);
+    // fp32: the register-staged kernel wins below ~2 tiles per CU; split-bf16: its fp32 MFMAs cost 5x more than
+    // the DMA kernel's, so the DMA kernel is taken from half a wave of tiles on
+    const long min_tiles = g_conv_math == 1 ? 128 : 512;
+    const bool wide = g.K >= 128 && ((long)nbm * cdiv(g.K, 128) >= min_tiles || force);
     const long b64 = (long)nbm * cdiv(g.K, 64);
-    if (wide || b64 >= 512 || force) {
+    if (wide || b64 >= min_tiles || force) {
 #define SRHIP_LD(BN_, EPI_)                                                                                        \
   do {                                                                                                             \
     const int nbn = cdiv(g.K, BN_);                                                                                \
