@@ -224,45 +224,43 @@ __global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const floa
 // ---- B2b: dw7[ch][kh][kw] = sum_pix da[pix] * pooled[(y+kh-3, x+kw-3)][ch] ---------------------------- //
 // Every thread takes one pixel and all 98 taps (register accumulators), waves reduce with shuffles,
 // the block writes one 98-vector of partials; slam_conv7_wgrad_reduce_kernel sums the block partials.
-constexpr int W7_BLOCKS = 384;
+// A block stages a strip of W7_ROWS image rows (gradient + the 3-pixel halo of the pooled map) in LDS; thread
+// (tap, half) then walks half of the strip's pixels with one multiply-add per pixel -- no per-thread tap array,
+// no cross-lane reduction (the first version kept 98 accumulators per pixel-thread and spent its time in 98
+// wave reductions: 53 us for 9 MFLOP).  part[tap][block] feeds slam_conv7_wgrad_reduce_kernel.
+constexpr int W7_ROWS = 8;
 __global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __restrict__ da,
                                                                 const float2* __restrict__ pooled,
-                                                                float* __restrict__ part, int h, int w, long npix) {
-  __shared__ float red[4][98];
-  const int hw = h * w;
-  float acc[98];
-#pragma unroll
-  for (int t = 0; t < 98; ++t) acc[t] = 0.f;
-  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
-    const long b = pix / hw;
-    const int rem = (int)(pix - b * hw);
-    const int y = rem / w, x = rem - y * w;
-    const float g = da[pix];
-    const float2* img = pooled + b * hw;
-#pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
-      const int yy = y + kh - 3;
-      const bool yok = yy >= 0 && yy < h;
-#pragma unroll
-      for (int kw = 0; kw < 7; ++kw) {
-        const int xx = x + kw - 3;
-        float2 p = make_float2(0.f, 0.f);
-        if (yok && xx >= 0 && xx < w) p = img[yy * w + xx];
-        acc[kh * 7 + kw] += g * p.x;
-        acc[49 + kh * 7 + kw] += g * p.y;
-      }
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int t = 0; t < 98; ++t) {
-    const float v = wave_sum(acc[t]);
-    if (lane == 0) red[wave][t] = v;
+                                                                float* __restrict__ part, int h, int w, int strips) {
+  extern __shared__ __attribute__((aligned(16))) float w7lds[];
+  const int b = blockIdx.x / strips, sidx = blockIdx.x - b * strips;
+  const int y0 = sidx * W7_ROWS;
+  const int rows = min(W7_ROWS, h - y0);
+  const int wp = w + 6;
+  float* g = w7lds;                                   // [W7_ROWS][w]
+  float2* pl = reinterpret_cast<float2*>(w7lds + W7_ROWS * w);   // [W7_ROWS + 6][w + 6], zero outside the image
+  const size_t img = (size_t)b * h * w;
+  for (int i = threadIdx.x; i < rows * w; i += 256) g[i] = da[img + (size_t)y0 * w + i];
+  for (int i = threadIdx.x; i < (rows + 6) * wp; i += 256) {
+    const int r = i / wp, c = i - r * wp;
+    const int yy = y0 + r - 3, xx = c - 3;
+    pl[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? pooled[img + (size_t)yy * w + xx] : make_float2(0.f, 0.f);
   }
   __syncthreads();
-  if (threadIdx.x < 98)                              // tap-major partials: the reduce reads them contiguously
-    part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  const int t = threadIdx.x >> 1, half = threadIdx.x & 1;
+  if (t < 98) {
+    const int ch = t >= 49, tt = t - 49 * ch;
+    const int kh = tt / 7, kw = tt - kh * 7;
+    const float* src = reinterpret_cast<const float*>(pl) + ch;
+    float acc = 0.f;
+    for (int r = half; r < rows; r += 2) {
+      const float* grow = g + r * w;
+      const float* prow = src + 2 * ((r + kh) * wp + kw);
+      for (int x = 0; x < w; ++x) acc += grow[x] * prow[2 * x];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) part[(size_t)t * gridDim.x + blockIdx.x] = acc;   // tap-major partials: the reduce reads them contiguously
+  }
 }
 __global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw7, int nblk,
                                                int accumulate) {
@@ -432,7 +430,7 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
 }
 
 size_t srhip_attn_tail_bwd_workspace(int n, int h, int w) {
-  return ((size_t)n * h * w * 3 + (size_t)n * TAIL_BLK * TC + (size_t)W7_BLOCKS * 98) * sizeof(float);
+  return ((size_t)n * h * w * 3 + (size_t)n * TAIL_BLK * TC + (size_t)n * cdiv(h, W7_ROWS) * 98) * sizeof(float);
 }
 
 int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s, const float* m, const float* pooled,
@@ -451,8 +449,10 @@ int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s,
   float* w7part = dsp + (size_t)n * TAIL_BLK * TC;
   hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
   hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
-  const int w7blk = (int)(cdiv(npix, 256) < W7_BLOCKS ? cdiv(npix, 256) : W7_BLOCKS);
-  hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), 0, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, npix);
+  const int strips = (int)cdiv(h, W7_ROWS), w7blk = n * strips;
+  const size_t w7lds = ((size_t)W7_ROWS * w + 2 * (size_t)(W7_ROWS + 6) * (w + 6)) * sizeof(float);
+  SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd_spatial: image too wide for the 7x7 weight-gradient strip");
+  hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), w7lds, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, strips);
   hipLaunchKernelGGL(slam_conv7_wgrad_reduce_kernel, dim3(98), dim3(64), 0, st, w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(tail_bwd_main_kernel, dim3(TAIL_BLK, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw);
   hipLaunchKernelGGL(tail_bwd_ds_kernel, dim3(n), dim3(TC), 0, st, dsp, ds, TAIL_BLK);

@@ -55,10 +55,17 @@ def grad_score(hip_nets, ora_nets, floor=1e-2, verbose=False):
     return (rows[0][0], rows[0][1]) if rows else (0.0, '')
 
 
-def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, golden=None):
+def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, golden=None, fp64_ref=False):
     """Runs `iters` training iterations on both paths; returns the max abs scalar diff and the worst
     gradient score (grad_score) over the iterations.  With `golden` (npz from the reference) the HIP
     scalars are also checked against it.
+
+    fp64_ref: the discriminator's gradient is dominated by the WGAN-GP double backward through train-mode
+    BatchNorm and is ill-conditioned: the reference's own fp32 arithmetic (the fp32 oracle) is 1.4e-2 away from an
+    fp64 evaluation of the same graph at full size (tools/grad_noise.py).  With fp64_ref the first iteration is also
+    run in fp64 on the CPU and the HIP gradients are scored against THAT: G under the absolute 5e-3 bar, D within
+    max(2e-2, twice the fp32 oracle's own distance from fp64) -- i.e. as accurate as the reference's arithmetic to
+    within a factor of two, whichever conv arithmetic mode is active.
 
     Post-step WEIGHTS are not compared element-wise: Adam turns every gradient into a step of
     ~lr*sign(g), so an element whose true gradient is (near) zero moves by +-lr on ANY two platforms
@@ -79,6 +86,13 @@ def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, 
             alpha = torch.from_numpy(golden['alpha%d' % it])
         else:
             alpha = O.det_fill('%s.alpha.%d' % (tag, it), (batch, 1, 1, 1), 0.5, 0.5)
+        ref64 = None
+        if fp64_ref and it == 0:
+            import copy
+            g64, d64, f64 = (copy.deepcopy(m).double() for m in (og, od, of))
+            O.train_step(g64, d64, f64, torch.optim.Adam(g64.parameters(), lr=2e-4), torch.optim.Adam(d64.parameters(), lr=2e-4),
+                         lr_img.double(), hr_img.double(), alpha.double())
+            ref64 = (g64, d64)
         want = O.train_step(og, od, of, oG, oD, lr_img, hr_img, alpha)
         got = step(lr_img.to(device), hr_img.to(device), alpha.to(device))
         gv = np.array([float(got[k]) for k in names])
@@ -96,7 +110,16 @@ def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, 
             # through train-mode BatchNorm (weight 1+lambda = 11), which is ill-conditioned in fp32 on any
             # platform (the reference-recorded vectors in test_gradient_penalty_double_backward carry 5e-3):
             # normalise both to the common 5e-3 bar.
-            gscore = max(gscore, sg, sd * (5e-3 / 2e-2))
+            d_bar = 2e-2
+            if ref64 is not None:
+                sg, kg = grad_score((hg,), (ref64[0],))
+                sd, kd = grad_score((hd,), (ref64[1],))
+                rg, _ = grad_score((og,), (ref64[0],))
+                rd, _ = grad_score((od,), (ref64[1],))
+                d_bar = max(2e-2, 2.0 * rd)
+                print('train_parity[%s] vs fp64 oracle: HIP G %.3e (%s) D %.3e (%s); fp32 oracle itself G %.3e D %.3e; D bar %.3e'
+                      % (tag, sg, kg, sd, kd, rg, rd, d_bar))
+            gscore = max(gscore, sg, sd * (5e-3 / d_bar))
             for (k, a), (_, b) in zip(hd.state_dict().items(), od.state_dict().items()):
                 if 'running_' in k:                      # BatchNorm running statistics after the first 4 updates
                     gscore = max(gscore, rel_err(a, b))

@@ -168,8 +168,9 @@ def test_train_two_iterations_small(golden):
 
 
 def test_train_two_iterations_full_size(golden):
-    """x4, 54->216, 12 groups x 3 RAB, B=2: losses/PSNR-relevant scalars within 1e-3 of the reference."""
-    worst, wdiff = train_parity(DEV, 'train_full', 12, 3, 2, 54, 4, 2, golden('train_full'))
+    """x4, 54->216, 12 groups x 3 RAB, B=2: losses/PSNR-relevant scalars within 1e-3 of the reference; gradients of
+    the first iteration scored against an fp64 evaluation of the same graph (parity_util.train_parity, fp64_ref)."""
+    worst, wdiff = train_parity(DEV, 'train_full', 12, 3, 2, 54, 4, 2, golden('train_full'), fp64_ref=True)
     assert worst < TOL and wdiff < 5e-3, (worst, wdiff)
 
 
