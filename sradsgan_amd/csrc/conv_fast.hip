@@ -1304,6 +1304,225 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
   if (want_bias && m0 + tid < g.K) bias_partial[(size_t)split * g.K + m0 + tid] = bsum;
 }
 
+// ================================================================================================ //
+// wgrad of stride-1 pad-1 3x3 convolutions in split-bf16, "row-tap" form.
+// fast_wgrad_dma_kernel<.., MATH 1> is VALU-issue bound (14-22 VALU per MFMA: every wave splits every fragment,
+// and for Cin = 64 the nine tap tiles each re-fetch and re-split the same dy pixels).  Here
+//   * a K chunk is 16 output pixels of ONE image row, so (image, row, first column) are scalars;
+//   * a block owns [BM output channels] x [one filter row kh, a slice of 64 input channels, ALL THREE kw]:
+//     the three kw taps read the same input row shifted by one pixel, so the x operand is staged once as an
+//     18-pixel segment and a lane builds its three B fragments from 10 gathered values (one split, two funnel
+//     shifts) instead of 24; the dy operand is fetched and split once for the three taps.
+//   18 MFMAs per wave and chunk for ~75 VALU (fast_wgrad_dma_kernel: 6 MFMAs for ~90).
+// LDS: 3-slot ring of [16 px][BM] dy + [20 px][64] x (fp32, lane-linear LDS-DMA images); same split-K partial
+// layout, reduce kernel and XCD mapping as the other wgrad kernels.
+// ================================================================================================ //
+template <int BM, int CIS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_rowtap_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    float* __restrict__ bias_partial, WgradGeom g, int nseg, int chunks_per_split) {
+  // tile = BM output channels x (one kh, CIS input channels, three kw); 128 x 64 for wide layers, 64 x 128 for Cout = 64
+  constexpr int WM = BM / 64, WN = 4 / WM;          // a wave owns 64 co x (3 kw x 32 ci)
+  constexpr int NCI = CIS / WN;
+  static_assert((BM == 128 && CIS == 64) || (BM == 64 && CIS == 128), "tile shapes");
+  static_assert(NCI == 32, "32 input channels per wave");
+  constexpr int TM = 2, TN = 3;                     // TN = kw
+  constexpr int A_B = BM * 64;                      // [16 px][BM] fp32
+  constexpr int B_B = 20 * CIS * 4;                 // [20 px][CIS] fp32 (18 used)
+  constexpr int STAGE_B = A_B + B_B;
+  constexpr int NA = A_B / 1024 / 4;                // A pieces per wave
+  constexpr int NBT = B_B / 1024;                   // B pieces per chunk, dealt to the waves in order
+  constexpr int RPA = 1024 / (BM * 4), RPB = 1024 / (CIS * 4);   // pixel rows per piece
+  constexpr int EPI_B = 4 * 32 * 32 * 4;
+  constexpr int LDS_B = 3 * STAGE_B > EPI_B ? 3 * STAGE_B : EPI_B;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncs = g.C / CIS;                        // channel slices of the input
+  const int ntn = 3 * ncs;                          // N tiles: (kh, ci slice)
+  const int ntm = (g.K + BM - 1) / BM;
+  int tile_n, tile_m, split;                        // XCD-aware order, as in fast_wgrad_kernel
+  {
+    const int tps = ntm * ntn;
+    int bid = blockIdx.x;
+    if (g.nsplit % 8 == 0) {
+      const int j = bid >> 3;
+      split = (j / tps) * 8 + (bid & 7);
+      bid = j % tps;
+    } else {
+      split = bid / tps;
+      bid -= split * tps;
+    }
+    tile_n = bid % ntn;
+    tile_m = bid / ntn;
+  }
+  const int kh = tile_n / ncs, cs = tile_n - kh * ncs;
+  const int m0 = tile_m * BM, ci_base = cs * CIS;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+  const int nchunks_total = g.N * g.Ho * nseg;
+  const int c_begin = split * chunks_per_split;
+  const int c_end = min(c_begin + chunks_per_split, nchunks_total);
+  const int nk = c_end - c_begin;
+
+  // DMA lanes.  A (dy): RPA pixel rows per 1 KiB piece, NA pieces per wave.  B (x): RPB staged pixel rows per piece,
+  // NBT pieces dealt to the waves in order (wave-uniform counts nb)
+  const int a_col = lane % (BM / 4), a_rsub = lane / (BM / 4);
+  const bool a_colok = (m0 + a_col * 4) < g.K;
+  const int b_col = lane % (CIS / 4), b_rsub = lane / (CIS / 4);
+  const int nb = NBT / 4 + (wave < NBT % 4 ? 1 : 0);
+  const int b_first = wave * (NBT / 4) + (wave < NBT % 4 ? wave : NBT % 4);
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * NA * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + A_B + b_first * 1024);
+
+  int i_n, i_ho, i_seg;                             // chunk the next issue() fetches (scalars)
+  {
+    i_seg = c_begin % nseg;
+    const int t = c_begin / nseg;
+    i_ho = t % g.Ho;
+    i_n = t / g.Ho;
+  }
+  auto issue = [&](int slot) {
+    const int wo0 = i_seg * 16;
+    const long prow = ((long)i_n * g.Ho + i_ho) * g.Wo + wo0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = (wave * NA + i) * RPA + a_rsub;            // output pixel slot 0..15
+      const float* ptr = (a_colok && wo0 + j < g.Wo) ? dy + ((prow + j) * g.ldy + m0 + a_col * 4) : g_zero16;
+      lds_dma16(ptr, a_dst + slot * STAGE_B + i * 1024);
+    }
+    const int hi = i_ho - 1 + kh;
+    const bool rowok = hi >= 0 && hi < g.H;
+    const long xrow = ((long)i_n * g.H + hi) * g.W;
+#pragma unroll
+    for (int i = 0; i < NBT / 4 + 1; ++i) {
+      if (i < nb) {
+        const int r = (b_first + i) * RPB + b_rsub;            // staged pixel row: input column wo0 - 1 + r
+        const int wi = wo0 - 1 + r;
+        const bool ok = rowok && r < 18 && wi >= 0 && wi < g.W;
+        const float* ptr = ok ? x + ((xrow + wi) * g.ldx + ci_base + b_col * 4) : g_zero16;
+        lds_dma16(ptr, b_dst + slot * STAGE_B + i * 1024);
+      }
+    }
+    if (++i_seg == nseg) {
+      i_seg = 0;
+      if (++i_ho == g.Ho) {
+        i_ho = 0;
+        ++i_n;
+      }
+    }
+  };
+  auto wait_chunk = [&](bool more) {                // this wave's pieces of the oldest chunk in flight have landed
+    if (!more) {
+      wait_vmcnt<0>();
+    } else if (nb == NBT / 4 + 1) {
+      wait_vmcnt<NA + NBT / 4 + 1>();
+    } else {
+      wait_vmcnt<NA + NBT / 4>();
+    }
+  };
+
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  // fragment gather offsets inside a stage (bytes): A value j of tile t = raw A[(8 khalf + j)][wm*64 + t*32 + l31];
+  // B value j (0..9) = staged row 8 khalf + j, channel wn*32 + l31
+  const int a_off = (8 * khalf) * BM * 4 + (wm * 64 + l31) * 4;
+  const int b_off = A_B + (8 * khalf) * CIS * 4 + (wn * NCI + l31) * 4;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = bias_partial != nullptr && tile_n == 0 && tid < BM;
+
+  if (nk > 0) {
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0, nstage = 2;
+    for (int kc = 0; kc < nk; ++kc) {
+      wait_chunk(kc + 1 < nk);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kc + 2 < nk) issue(nstage);
+      const char* sb = lds + stage * STAGE_B;
+      // A fragments: gather 8 pixels, split
+      bf16x8_t ah[TM], al[TM];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(sb + a_off + j * BM * 4 + t * 128);
+        split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ah[t], al[t]);
+      }
+      // B: 10 staged pixels -> packed hi/lo pairs P0..P4 -> the three kw fragments (kw 1 by a 16-bit funnel shift)
+      unsigned ph[5], pl[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float e0 = *reinterpret_cast<const float*>(sb + b_off + (2 * i) * CIS * 4);
+        const float e1 = *reinterpret_cast<const float*>(sb + b_off + (2 * i + 1) * CIS * 4);
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t h = {(__bf16)e0, (__bf16)e1};
+        ph[i] = __builtin_bit_cast(unsigned, h);
+        const bf16x2_t l = {(__bf16)(e0 - __uint_as_float(ph[i] << 16)), (__bf16)(e1 - __uint_as_float(ph[i] & 0xffff0000u))};
+        pl[i] = __builtin_bit_cast(unsigned, l);
+      }
+      bf16x8_t bh[TN], bl[TN];
+      {
+        const u32x4 h0 = {ph[0], ph[1], ph[2], ph[3]}, l0 = {pl[0], pl[1], pl[2], pl[3]};
+        const u32x4 h2 = {ph[1], ph[2], ph[3], ph[4]}, l2 = {pl[1], pl[2], pl[3], pl[4]};
+        const u32x4 h1 = {__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
+                          __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16)};
+        const u32x4 l1 = {__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
+                          __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16)};
+        bh[0] = __builtin_bit_cast(bf16x8_t, h0); bl[0] = __builtin_bit_cast(bf16x8_t, l0);
+        bh[1] = __builtin_bit_cast(bf16x8_t, h1); bl[1] = __builtin_bit_cast(bf16x8_t, l1);
+        bh[2] = __builtin_bit_cast(bf16x8_t, h2); bl[2] = __builtin_bit_cast(bf16x8_t, l2);
+      }
+#pragma unroll
+      for (int i = 0; i < 3 * TM * TN; ++i) {
+        const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+      }
+      if (want_bias) {
+        const float* col = reinterpret_cast<const float*>(sb) + tid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum += col[r * BM];
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+      nstage = nstage == 2 ? 0 : nstage + 1;
+    }
+  }
+
+  // partial tile -> LDS (wave-private 32x32 region) -> row-contiguous 16-byte stores; sub-tile u is tap (kh, kw = u)
+  float* out = partial + (size_t)split * g.K * g.Ktot;
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(lds) + wave * (32 * 32);
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + l31] = acc[t][u][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane;
+        const int row = idx >> 3, cq = idx & 7;
+        const float4 v = *reinterpret_cast<const float4*>(wl + row * 32 + cq * 4);
+        const int m = m0 + wm * 64 + t * 32 + row;
+        const int n = (kh * 3 + u) * g.C + ci_base + wn * NCI + cq * 4;
+        if (m < g.K) *reinterpret_cast<float4*>(out + (size_t)m * g.Ktot + n) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (want_bias && m0 + tid < g.K) bias_partial[(size_t)split * g.K + m0 + tid] = bsum;
+}
+
 // partial[s][co][(tap,ci)] --sum over s--> dw[co][ci][kh][kw];  bias_partial[s][co] --> db[co]
 __global__ __launch_bounds__(256) void fast_wgrad_reduce_kernel(const float* __restrict__ partial,
                                                                  const float* __restrict__ bias_partial,
@@ -1599,7 +1818,16 @@ struct FastWgradPlan {
   int bm, bn, bk, nsplit, chunks_per_split;
 };
 int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, +10: register-staged kernel
-static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
+// row-tap kernel (wgrad_rowtap_kernel): split-bf16, 3x3 stride 1 pad 1, Cin % 64 == 0, Cout % 4 == 0 (g_wgrad_cfg 7 turns it off)
+static int rowtap_ok(int cin, int cout, int kh, int kw, int stride, int pad) {   // 0: no, 1: 128 x (kh, 64 ci), 2: 64 x (kh, 128 ci)
+  if (!(g_conv_math == 1 && g_wgrad_cfg != 7 && (g_wgrad_cfg < 10 || g_wgrad_cfg >= 100) && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout % 4 == 0))
+    return 0;
+  if (cout >= 128 && cin % 64 == 0) return 1;
+  if (cout == 64 && cin % 128 == 0) return 2;
+  return 0;
+}
+
+static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot, int rowtap = 0) {
   FastWgradPlan p;
   p.bm = cout > 64 ? 128 : 64;
   p.bn = (ktot % 128 == 0) ? 128 : 64;            // Ktot = 9*64 tiles exactly by 64, not by 128
@@ -1614,9 +1842,14 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot) {
   // split-bf16 wgrad is VALU-issue bound (every wave splits the fragments it reads): where Ktot only tiles by 64
   // (Cin = 64), a 256 x 64 tile doubles the MFMAs per split fragment (measured -10 % on 64->256 convs)
   if (g_conv_math == 1 && g_wgrad_cfg == 0 && p.bn == 64 && cout % 256 == 0) p.bm = 256;
+  if (rowtap == 1) { p.bm = 128; p.bn = 192; }
+  if (rowtap == 2) { p.bm = 64; p.bn = 384; }
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
   const int nchunks = cdiv(P, p.bk);
-  long ns = (640 + tiles - 1) / tiles;               // ~2.5 blocks per CU overall
+  // blocks aimed at: ~2.5 per CU; the row-tap kernel runs 3 per CU and is fastest with exactly one full wave of
+  // blocks (768: measured 0.161 -> 0.128 ms on RAB conv1 against 640; 512 and 1024 are both slower)
+  const long target = rowtap ? (g_wgrad_cfg >= 100 ? g_wgrad_cfg : 768) : 640;
+  long ns = (target + tiles - 1) / tiles;
   const long maxsplit = (nchunks + 15) / 16;          // at least 16 chunks (256 pixels) per split
   if (ns > maxsplit) ns = maxsplit;
   if (ns > 256) ns = 256;
@@ -1632,7 +1865,7 @@ size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int k
   const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
   const long P = (long)n * ho * wo;
   if (P <= 0) return 0;
-  FastWgradPlan p = plan_fast_wgrad(P, cout, kh * kw * cin);
+  FastWgradPlan p = plan_fast_wgrad(P, cout, kh * kw * cin, rowtap_ok(cin, cout, kh, kw, stride, pad));
   return (size_t)p.nsplit * ((size_t)cout * kh * kw * cin + cout) * sizeof(float);
 }
 
@@ -1652,7 +1885,9 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   g.P = (int)P; g.Ktot = kh * kw * cin;
   SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.x_bytes) && bytes_ok(P, ldy, cout, &g.dy_bytes),
                 "conv2d_wgrad: tensor >= 2 GiB");
-  FastWgradPlan p = plan_fast_wgrad(P, cout, g.Ktot);
+  // (an operand-scaled 3x3 would plan without row-tap and may then need more workspace than the query reported)
+  const int rowtap = (!xrow && !xchan) ? rowtap_ok(cin, cout, kh, kw, stride, pad) : 0;
+  FastWgradPlan p = plan_fast_wgrad(P, cout, g.Ktot, rowtap);
   g.nsplit = p.nsplit; g.chunks_per_split = p.chunks_per_split;
   const size_t need = (size_t)p.nsplit * ((size_t)cout * g.Ktot + cout) * sizeof(float);
   if (!workspace || workspace_bytes < need) {
@@ -1677,7 +1912,16 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
       hipLaunchKernelGGL((fast_wgrad_kernel<BM_, BN_, WM_, WN_>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
                          db ? bias_partial : nullptr, xrow, xchan, g);                                           \
   } while (0)
-  if (p.bm == 256 && p.bn == 64)
+  if (rowtap) {
+    const int nseg = cdiv(g.Wo, 16);
+    const int cps = cdiv(g.N * g.Ho * nseg, p.nsplit);
+    if (rowtap == 1)
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
+                         db ? bias_partial : nullptr, g, nseg, cps);
+    else
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
+                         db ? bias_partial : nullptr, g, nseg, cps);
+  } else if (p.bm == 256 && p.bn == 64)
     SRHIP_LW(256, 64, 4, 1);
   else if (p.bm == 64 && p.bn == 256)
     SRHIP_LW(64, 256, 1, 4);

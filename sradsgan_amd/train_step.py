@@ -36,7 +36,7 @@ def _ptr(t):
 class TrainStep:
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
-                 grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True):
+                 grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True, overlap_d_step=True):
         self.G, self.D, self.F = generator, discriminator, feature_extractor
         self.weight_content, self.weight_gan = weight_content, weight_gan
         self.lambda_gp, self.clip_value, self.use_gp = lambda_gp, clip_value, use_gp
@@ -47,6 +47,10 @@ class TrainStep:
         self.use_graph = use_graph
         self.reuse_d_fake = reuse_d_fake
         self.overlap_wgrad = overlap_wgrad
+        self.overlap_d_step = overlap_d_step and os.environ.get('SRHIP_OVERLAP_D', '1') == '1'
+        if self.overlap_d_step and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+            # D's parameters are used on both streams by design; the engine orders their AccumulateGrad nodes itself
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = self.arena_G.flat_p.device
         self._wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
@@ -139,21 +143,45 @@ class TrainStep:
             bn._stat_stash = None
         loss_gan = -d_gen.mean()
         loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
-        with ops.backward_scope(skip_params=d_params):            # no discriminator wgrads in the G step (:857 -> :865)
-            torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
-        # ---------------- discriminator (sradsgan.py:865-886) ----------------
-        loss_D = -D(imgs_hr).mean() + d_gen.mean()                # update #2 (real)
-        ops.replay_bn_update(stash)                               # update #3 (the fake pass that is not recomputed)
-        fake = gen_hr.detach()
-        if self.use_gp:
-            gp = self.gradient_penalty(imgs_hr, fake, alpha)      # update #4
-            total = loss_D + (1.0 + self.lambda_gp) * gp          # :639 + :884-886 => 1 + lambda
-            loss_D = loss_D + self.lambda_gp * gp
+
+        def d_forward():
+            # ---------------- discriminator forward passes (sradsgan.py:865-884) ----------------
+            loss_D = -D(imgs_hr).mean() + d_gen.mean()            # update #2 (real)
+            ops.replay_bn_update(stash)                           # update #3 (the fake pass that is not recomputed)
+            fake = gen_hr.detach()
+            if self.use_gp:
+                gp = self.gradient_penalty(imgs_hr, fake, alpha)  # update #4
+                total = loss_D + (1.0 + self.lambda_gp) * gp      # :639 + :884-886 => 1 + lambda
+                loss_D = loss_D + self.lambda_gp * gp
+            else:
+                gp = torch.zeros((), device=imgs_hr.device)
+                total = loss_D
+            return loss_D, gp, total, fake
+
+        if side is not None and self.overlap_d_step:
+            # The discriminator's real / interpolate passes (incl. the first-order backward of the penalty) depend
+            # on gen_hr and D's weights only, not on the generator's backward: enqueue them on the side stream
+            # BEFORE the generator's backward so the two chains run concurrently on the GPU.  autograd replays every
+            # node on the stream of its forward, so their double backward stays on the side stream too.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)                                # gen_hr, d_gen and running-stat update #1 are in
+            with torch.cuda.stream(side):
+                loss_D, gp, total, fake = d_forward()
+            for t in (gen_hr, d_gen, alpha):
+                t.record_stream(side)
+            with ops.backward_scope(skip_params=d_params):        # no discriminator wgrads in the G step (:857 -> :865)
+                torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+            with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
+                torch.autograd.backward(total, inputs=d_params)
+            main.wait_stream(side)
+            for t in (loss_D, gp):
+                t.record_stream(main)
         else:
-            gp = torch.zeros((), device=imgs_hr.device)
-            total = loss_D
-        with ops.backward_scope(stop_at=(gen_hr,)):               # d/d(gen_hr) is not needed any more
-            torch.autograd.backward(total, inputs=d_params)
+            with ops.backward_scope(skip_params=d_params):
+                torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+            loss_D, gp, total, fake = d_forward()
+            with ops.backward_scope(stop_at=(gen_hr,)):
+                torch.autograd.backward(total, inputs=d_params)
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
 
