@@ -127,7 +127,7 @@ def time_dominant_kernel(device, batch):
             traffic = {}
     out = []
     kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_kernel<128,bias+lrelu>'}[math]
-    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'fast_wgrad_dma_kernel<256,64,bf16x3>'}[math]
+    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>'}[math]
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
             ('wgrad', kw + ' + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
@@ -345,10 +345,17 @@ def main():
         line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
-        print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush that first so the JSON line is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
