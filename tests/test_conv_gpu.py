@@ -255,3 +255,51 @@ def test_conv_math_modes_against_fp64(mode, tol):
     assert _rel(dx, ref_dx) < tol
     assert _rel(dw, ref_dw) < tol
     assert _rel(db, dyd.sum((0, 2, 3))) < 5e-6
+
+
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (3, 256, 9, 20, 256), (2, 64, 27, 27, 512)])
+def test_patch_conv_kernel_bit_identical_to_dma_kernel(case):
+    """conv_patch_kernel (resident halo patch, in-place hi/lo conversion) must reproduce fast_conv_dma_kernel<bf16x3>
+    bit for bit -- same split, same product and chunk order -- on ragged images (edge patches, dead GEMM rows), for
+    fprop with bias+LeakyReLU and for dgrad with activation mask + residual."""
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev))
+    b = torch.randn(cout, generator=g).to(dev)
+    dy = torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    out = {}
+    with ops.conv_math('bf16x3'):
+        for cfg in (-1, -2):                     # -1: force the LDS-DMA kernel, -2: force the patch kernel
+            lib.srhip_debug_set(0, cfg)
+            try:
+                out[cfg] = (ops.conv2d_fwd_raw(x, wt, b, 1, 1, 0.2), ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), 1, 1, r, x, 0.2))
+            finally:
+                lib.srhip_debug_set(0, 0)
+    assert torch.equal(out[-1][0], out[-2][0])
+    assert torch.equal(out[-1][1], out[-2][1])
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
+    assert _rel(out[-2][0], ref) < 1.5e-5
+
+
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256)])
+def test_rowtap_wgrad_against_fp64(case):
+    """wgrad_rowtap_kernel (both tile shapes) on ragged widths: rows padded to 16-pixel chunks, 18-pixel staged
+    segments crossing the image border, funnel-shifted kw = 1 fragments; weight and bias gradients vs fp64."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    dyg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+    with ops.conv_math('bf16x3'):
+        dw, db = ops.conv2d_wgrad_raw(xg, dyg, (cout, cin, 3, 3), 1, 1, True)
+    assert _rel(dw, ref) < 1.5e-5
+    assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
