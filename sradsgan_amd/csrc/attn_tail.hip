@@ -13,7 +13,7 @@
 namespace srhip {
 
 constexpr int TC = 64;          // channels
-constexpr int SEG = 8;          // pooling segments per image
+constexpr int SEG = 32;         // pooling segments per image (32 x batch blocks: 8 left most CUs idle at B = 32)
 
 __device__ inline float group16_sum(float v) {
 #pragma unroll
@@ -400,7 +400,7 @@ __global__ void clam_mlp_bwd_reduce_kernel(const float* __restrict__ pw1, const 
   *o = accumulate ? *o + acc : acc;
 }
 
-constexpr int TAIL_BLK = 16;     // blocks per image in tail_bwd_main
+constexpr int TAIL_BLK = 48;     // blocks per image in tail_bwd_main
 
 }  // namespace srhip
 

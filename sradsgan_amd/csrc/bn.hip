@@ -322,7 +322,7 @@ __global__ void bn_bwd2_apply_kernel(const float* __restrict__ u, const float* _
 
 static long bn_nblk(long rows) {
   long nblk = (rows + 63) / 64;
-  return nblk > 256 ? 256 : (nblk < 1 ? 1 : nblk);
+  return nblk > 1024 ? 1024 : (nblk < 1 ? 1 : nblk);   // 4 blocks per CU: 256 could not saturate HBM
 }
 
 }  // namespace srhip

@@ -1852,7 +1852,7 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot, int rowtap = 0)
   long ns = (target + tiles - 1) / tiles;
   const long maxsplit = (nchunks + 15) / 16;          // at least 16 chunks (256 pixels) per split
   if (ns > maxsplit) ns = maxsplit;
-  if (ns > 256) ns = 256;
+  if (ns > (tiles <= 2 ? 768 : 256)) ns = tiles <= 2 ? 768 : 256;   // one- and two-tile GEMMs (1x1, 64 -> 64) still want a full wave of blocks
   if (ns < 1) ns = 1;
   if (ns >= 8) ns = (ns + 7) / 8 * 8;                  // multiples of 8: one split per XCD lane (see kernels)
   p.chunks_per_split = (int)((nchunks + ns - 1) / ns);
