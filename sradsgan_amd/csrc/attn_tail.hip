@@ -64,15 +64,19 @@ __global__ void clam_pool_partial_kernel(const float* __restrict__ u, float* __r
 }
 
 // ---- F1b: combine segments, shared MLP 64 -> 4 -> 64 (no bias), sigmoid -> s[b,c] ---------------- //
-__global__ void clam_mlp_kernel(const float* __restrict__ psum, const float* __restrict__ pmax,
-                                const int* __restrict__ parg, const float* __restrict__ fc1,
-                                const float* __restrict__ fc2, float* __restrict__ avg, float* __restrict__ mx,
-                                int* __restrict__ arg, float* __restrict__ s, int hw, int hidden) {
-  __shared__ float sa[TC], sm[TC], ha[16], hm[16];
-  const int b = blockIdx.x, c = threadIdx.x;
+// 256 threads per image: 4 lanes per channel walk the segments, 16 lanes per hidden unit do the 64-long dot products
+// (one thread per channel with serial loops was latency-bound: 16 us for 64 x 4 numbers)
+__global__ __launch_bounds__(256) void clam_mlp_kernel(const float* __restrict__ psum, const float* __restrict__ pmax,
+                                                        const int* __restrict__ parg, const float* __restrict__ fc1,
+                                                        const float* __restrict__ fc2, float* __restrict__ avg,
+                                                        float* __restrict__ mx, int* __restrict__ arg,
+                                                        float* __restrict__ s, int hw, int hidden) {
+  __shared__ float sa[TC], sm[TC], ha[16], hm[16], qs[4][TC], qm[4][TC];
+  __shared__ int qa[4][TC];
+  const int b = blockIdx.x, c = threadIdx.x & 63, q = threadIdx.x >> 6;
   float sum = 0.f, m = -INFINITY;
   int am = 0x7fffffff;
-  for (int k = 0; k < SEG; ++k) {
+  for (int k = q; k < SEG; k += 4) {
     const int o = (b * SEG + k) * TC + c;
     sum += psum[o];
     const float v = pmax[o];
@@ -82,32 +86,62 @@ __global__ void clam_mlp_kernel(const float* __restrict__ psum, const float* __r
       am = a;
     }
   }
-  const float a_ = sum / (float)hw;
-  avg[b * TC + c] = a_;
-  mx[b * TC + c] = m;
-  arg[b * TC + c] = am;
-  sa[c] = a_;
-  sm[c] = m;
+  qs[q][c] = sum;
+  qm[q][c] = m;
+  qa[q][c] = am;
   __syncthreads();
-  if (c < hidden) {
-    float x0 = 0.f, x1 = 0.f;
-    for (int k = 0; k < TC; ++k) {
-      const float w = fc1[c * TC + k];
-      x0 += w * sa[k];
-      x1 += w * sm[k];
+  if (q == 0) {
+    sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sum += qs[k][c];      // segment order: (0,4,8,..) + (1,5,..) + ...
+    m = qm[0][c];
+    am = qa[0][c];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float v = qm[k][c];
+      const int a = qa[k][c];
+      if (v > m || (v == m && a < am)) {
+        m = v;
+        am = a;
+      }
     }
-    ha[c] = fmaxf(x0, 0.f);
-    hm[c] = fmaxf(x1, 0.f);
+    const float a_ = sum / (float)hw;
+    avg[b * TC + c] = a_;
+    mx[b * TC + c] = m;
+    arg[b * TC + c] = am;
+    sa[c] = a_;
+    sm[c] = m;
   }
   __syncthreads();
-  float l0 = 0.f, l1 = 0.f;
-  for (int j = 0; j < hidden; ++j) {
-    const float w = fc2[c * hidden + j];
-    l0 += w * ha[j];
-    l1 += w * hm[j];
+  {
+    const int j = threadIdx.x >> 4, part = threadIdx.x & 15;   // hidden unit j (<= 16), 4 inputs per lane
+    float x0 = 0.f, x1 = 0.f;
+    if (j < hidden) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = fc1[j * TC + part * 4 + k];
+        x0 += w * sa[part * 4 + k];
+        x1 += w * sm[part * 4 + k];
+      }
+    }
+    x0 = group16_sum(x0);
+    x1 = group16_sum(x1);
+    if (j < hidden && part == 0) {
+      ha[j] = fmaxf(x0, 0.f);
+      hm[j] = fmaxf(x1, 0.f);
+    }
   }
-  const float l = l0 + l1;
-  s[b * TC + c] = 1.f / (1.f + expf(-l));
+  __syncthreads();
+  if (q == 0) {
+    float l0 = 0.f, l1 = 0.f;
+    for (int j = 0; j < hidden; ++j) {
+      const float w = fc2[c * hidden + j];
+      l0 += w * ha[j];
+      l1 += w * hm[j];
+    }
+    const float l = l0 + l1;
+    s[b * TC + c] = 1.f / (1.f + expf(-l));
+  }
 }
 
 // ---- F2: pooled[pix] = (mean_c, max_c) of y = s*u, argc[pix] = first argmax channel -------------- //
@@ -423,7 +457,7 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
   float* pmax = psum + (size_t)n * SEG * TC;
   int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
   hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, hw);
-  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(TC), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden);
+  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(256), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden);
   hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
   hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
   return check_launch("attn_tail_fwd");

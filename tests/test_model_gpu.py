@@ -262,3 +262,22 @@ def test_device_validation_metrics_match_reference_arithmetic():
         assert abs(float(got['psnr'][b]) - O.psnr_u8(t_img, a_img)) < 1e-9
         assert abs(float(got['ergas'][b]) - O.ergas2(t_img, a_img, 4)) < 1e-9
         assert abs(float(got['ssim'][b]) - O.ssim_u8(a_img, t_img)) < 1e-9
+
+
+def test_graphed_evaluator_matches_eager_across_replays():
+    """The captured inference+metrics graph must reproduce the eager pass bit for bit on every replay, with device
+    syncs and fresh inputs in between (the training-step graph is not the default because its replay was racy)."""
+    from sradsgan_amd import model as M, validate
+    torch.manual_seed(3)
+    G = M.GeneratorResNet(M.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=4).to(DEV).eval()
+    ev = validate.GraphedEvaluator(G, 4)
+    for it in range(4):
+        lr = torch.rand(2, 3, 12, 10, device=DEV)
+        hr = torch.rand(2, 3, 48, 40, device=DEV)
+        want = validate.evaluate(G, lr, hr, 4)
+        torch.cuda.synchronize()
+        got = ev(lr, hr)
+        torch.cuda.synchronize()
+        assert torch.equal(got['recon'], want['recon']), it
+        for k in ('mse', 'psnr', 'ssim', 'ergas'):
+            assert torch.equal(got['sr'][k], want['sr'][k]), (it, k)
