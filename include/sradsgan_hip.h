@@ -38,7 +38,14 @@ extern "C" {
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
-/* experiment knobs for kernel tuning (key 0: fast-conv tile configuration, 0 = heuristic) */
+/* ABI 2: fast packed weights carry a second, pre-split bf16 section (srhip_packed_elems doubled for them);
+ * srhip_set_conv_math / srhip_get_conv_math added. */
+/* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
+ *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
+ *          20 register-staged kernels only, 21 no patch kernel, 1..8 fixed tile shapes of the register-staged kernel
+ *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, >= 10 register-staged
+ *          kernel, >= 100 split-K block target of the row-tap kernel
+ *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (timing only, wrong results) */
 int srhip_debug_set(int key, int value);
 
 /* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *
@@ -48,7 +55,9 @@ int srhip_debug_set(int key, int value);
  *   SRHIP_MATH_BF16X3  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16, with
  *                      ah = bf16(a), al = bf16(a - ah); per-product error <= ~2^-16, measured max error
  *                      of a 3x3x256 conv vs fp64: 4.5e-6 of max|y| (fp32 chain: 2e-6, TF32: ~5e-4)
- * Process-wide; applies to the LDS-DMA conv kernels (other shapes always use fp32).            */
+ * Process-wide.  Applies to every conv with source channels % 16 == 0 that is large enough for the LDS-DMA / patch /
+ * row-tap kernels and to the narrow-N (Cdst <= 32) kernel; the generic small-channel kernels and very small grids
+ * always compute in fp32.                                                                        */
 #define SRHIP_MATH_FP32 0
 #define SRHIP_MATH_BF16X3 1
 int srhip_set_conv_math(int mode);

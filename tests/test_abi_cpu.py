@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_pure_host_entry_points(lib):
-    assert lib.srhip_abi_version() >= 1
+    assert lib.srhip_abi_version() >= 2
     assert lib.srhip_packed_elems(256, 64, 3, 3, 0) == 2 * 256 * 64 * 9      # fast n-major layout: fp32 + split-bf16 sections
     assert lib.srhip_packed_elems(64, 3, 3, 3, 0) == 27 * 64                 # generic k-major, ld = 64
     assert lib.srhip_packed_elems(3, 64, 3, 3, 0) == 2 * 3 * 64 * 9 and lib.srhip_packed_elems(3, 64, 3, 3, 1) == 27 * 64
