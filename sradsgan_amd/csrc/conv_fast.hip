@@ -880,6 +880,107 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 }
 
 // ================================================================================================ //
+// Stride-1 3x3 convolutions with <= 4 destination channels (generator tail conv 64 -> 3, discriminator head dgrad
+// 64 -> 3) at full image size.  A 32-wide MFMA tile wastes 10x the arithmetic there and the op is HBM-bound
+// (one read of the source); this kernel does the 1728 multiply-adds per pixel on the VALU in exact fp32:
+//   * a block owns a 16 x 16 patch of output pixels, one thread per pixel, ND accumulators each;
+//   * the 18 x 18 halo of a 16-channel chunk is staged in LDS (double-buffered, coalesced 16-byte loads,
+//     16-byte slots XOR-swizzled by the pixel index so the nine shifted ds_read_b128 streams are conflict-free);
+//   * weights are indexed uniformly, so they arrive through scalar loads and enter the FMAs as SGPR operands.
+// ================================================================================================ //
+template <int ND>
+__global__ __launch_bounds__(256) void narrow_conv_kernel(const float* __restrict__ src, const float* __restrict__ wt,
+                                                           const float* __restrict__ bias, float* __restrict__ dst,
+                                                           FastGeom g, int tiles_h, int tiles_w, int lo_h, int lo_w) {
+  constexpr int PW = 16, PH = 16, PWP = PW + 2, PR = (PH + 2) * PWP;   // 324 patch rows of 64 B
+  __shared__ __attribute__((aligned(16))) float4 lds[2][PR * 4];
+  const int tid = threadIdx.x;
+  const int tpi = tiles_h * tiles_w;
+  const int img = blockIdx.x / tpi;
+  const int prem = blockIdx.x - img * tpi;
+  const int ty = prem / tiles_w, tx = prem - ty * tiles_w;
+  const int oh0 = ty * PH, ow0 = tx * PW;
+  const int py = tid >> 4, px = tid & 15;
+
+  // staging: 324 rows x 4 quads = 1296 float4 per chunk, 256 threads -> 6 per thread (last partially)
+  int soff[6];
+  int sdst[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int e = tid + i * 256;
+    soff[i] = -1;
+    sdst[i] = 0;
+    if (e < PR * 4) {
+      const int row = e >> 2, q = e & 3;
+      const int pi = row / PWP, pj = row - pi * PWP;
+      const int sh = oh0 + lo_h + pi, sw = ow0 + lo_w + pj;
+      sdst[i] = row * 4 + (q ^ (row & 3));
+      if (sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws) soff[i] = ((img * g.Hs + sh) * g.Ws + sw) * g.lds + q * 4;
+      else soff[i] = -2;                               // inside the patch, outside the image: zero
+    }
+  }
+  const int CC = g.C / 16;
+  float4 stage[6];
+  auto fetch = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      stage[i] = soff[i] >= 0 ? *reinterpret_cast<const float4*>(src + (size_t)soff[i] + cc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (soff[i] != -1) lds[buf][sdst[i]] = stage[i];
+  };
+  float acc[ND];
+#pragma unroll
+  for (int n = 0; n < ND; ++n) acc[n] = 0.f;
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int cc = 0; cc < CC; ++cc) {
+    const int buf = cc & 1;
+    if (cc + 1 < CC) fetch(cc + 1);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {              // not unrolled: one tap's 16 x ND weights fit the SGPR file
+      {
+        const int th = tap / 3, tw = tap - th * 3;
+        const int a_th = (g.dh0 + th * g.dhs) - lo_h, a_tw = (g.dw0 + tw * g.dws) - lo_w;
+        const int row = (py + a_th) * PWP + px + a_tw;
+        const int wk = ((g.kh0 + th * g.khs) * g.KW + (g.kw0 + tw * g.kws)) * g.C + cc * 16;   // uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = lds[buf][row * 4 + (q ^ (row & 3))];
+#pragma unroll
+          for (int n = 0; n < ND; ++n) {
+            const float* w = wt + (size_t)n * g.ldw + wk + q * 4;                              // scalar loads
+            acc[n] = fmaf(v.x, w[0], acc[n]);
+            acc[n] = fmaf(v.y, w[1], acc[n]);
+            acc[n] = fmaf(v.z, w[2], acc[n]);
+            acc[n] = fmaf(v.w, w[3], acc[n]);
+          }
+        }
+      }
+    }
+    if (cc + 1 < CC) commit(buf ^ 1);
+    __syncthreads();
+  }
+  const int oh = oh0 + py, ow = ow0 + px;
+  if (oh < g.OH && ow < g.OW) {
+    const size_t dpix = ((size_t)img * g.Hd + oh) * g.Wd + ow;
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      if (n < g.K) {
+        float v = acc[n];
+        if (g.flags & SRHIP_EPI_BIAS) v += bias[n];
+        if (g.flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
+        dst[dpix * g.ldd + n] = v;
+      }
+    }
+  }
+}
+
+// ================================================================================================ //
 // wgrad: dW[co][(tap,ci)] = sum_p dy[p][co] * xwin[p][(tap,ci)], split over pixel ranges.
 // Both operands are pixel-major, so the LDS images are k-major ([pixel][channel]) and fragments are
 // conflict-free ds_read_b32 of consecutive dwords.  Blocks with tile_n == 0 also emit the column sums
@@ -1649,6 +1750,18 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   if (g.M <= 0) return SRHIP_OK;
 #define SRHIP_LF(BM_, BN_, WM_, WN_, BK_) \
   return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
+  // <= 4 destination channels, stride-1 3x3, big image: exact-fp32 VALU kernel (both arithmetic modes; cfg 22 turns it off)
+  if (g.K <= 4 && g_fast_cfg != 20 && g_fast_cfg != 22 && g.TH == 3 && g.TW == 3 && g.ss == 1 && g.dsd == 1 && g.ph == 0 &&
+      g.pw == 0 && g.Hd == g.OH && g.Wd == g.OW && (g.dhs == 1 || g.dhs == -1) && (g.dws == 1 || g.dws == -1) &&
+      !(g.flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) && !g.accumulate && g.M >= 65536) {
+    const int th = cdiv(g.OH, 16), tw = cdiv(g.OW, 16);
+    const int lo_h = g.dhs > 0 ? g.dh0 : g.dh0 + 2 * g.dhs, lo_w = g.dws > 0 ? g.dw0 : g.dw0 + 2 * g.dws;
+    if (g.K == 3)
+      hipLaunchKernelGGL((narrow_conv_kernel<3>), dim3(g.N * th * tw), dim3(256), 0, st, src, wt, bias, dst, g, th, tw, lo_h, lo_w);
+    else
+      hipLaunchKernelGGL((narrow_conv_kernel<4>), dim3(g.N * th * tw), dim3(256), 0, st, src, wt, bias, dst, g, th, tw, lo_h, lo_w);
+    return check_launch("narrow_conv");
+  }
   if (g.K <= 32 && g_conv_math == 1 && g_fast_cfg != 20 && !(g.flags & (SRHIP_EPI_CHANSCALE | 0x300))) {
     const int nbm = cdiv(g.M, 128), nbn = cdiv(g.K, 32);
     hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,

@@ -405,6 +405,75 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
   }
 }
 
+
+// ---- weight gradient of 3x3 stride-1 pad-1 convs with <= 3 input channels (discriminator / VGG head, 3 -> 64) ---- //
+// dW[64][27] = dy^T [64 x pixels] . xcol [pixels x 27]: with the PIXELS as the contraction the exact-fp32 MFMA
+// (32x32x2) fits well -- M = 64 channels = two tiles, N = 27 columns padded to 32 -- and costs ~40 us of matrix time
+// for 1.5 M pixels; the generic kernel spent 1.1 ms on gather bookkeeping.  A block walks whole image rows: the
+// three input rows (zero halo) are staged in LDS; per pixel pair a wave issues two coalesced dy loads (A operand:
+// lane = channel, half-wave = pixel), one LDS gather (B operand: lane = column (tap, ci), half-wave = pixel) and two
+// MFMAs.  The four waves take interleaved pixel pairs and are summed through LDS at the end.
+__global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ partial, int N, int H, int W, int cin,
+                                                              int cout, int ldx, int ldy, int rows_per_split) {
+  extern __shared__ float xs[];                      // [3][W + 2][cin] (zero outside the image), then the reduce area
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int co0 = blockIdx.y * 64;
+  const int ktot = 9 * cin;
+  const int rowlen = (W + 2) * cin;
+  int koff = -1;                                     // LDS offset of this lane's column for output pixel 0
+  if (l31 < ktot) {
+    const int tap = l31 / cin, ci = l31 - tap * cin;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    koff = kh * rowlen + kw * cin + ci;
+  }
+  const bool c0ok = co0 + l31 < cout, c1ok = co0 + 32 + l31 < cout;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const int r_begin = blockIdx.x * rows_per_split, r_end = min(r_begin + rows_per_split, N * H);
+  for (int r = r_begin; r < r_end; ++r) {
+    const int n = r / H, oh = r - n * H;
+    __syncthreads();
+    for (int e = tid; e < 3 * rowlen; e += 256) {
+      const int kh = e / rowlen, rem = e - kh * rowlen;
+      const int col = rem / cin, ci = rem - col * cin;
+      const int ih = oh + kh - 1, iw = col - 1;
+      xs[e] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[((size_t)(n * H + ih) * W + iw) * ldx + ci] : 0.f;
+    }
+    __syncthreads();
+    const float* drow = dy + (size_t)r * W * ldy + co0 + l31;
+#pragma unroll 4
+    for (int ow = 2 * wave; ow < W; ow += 8) {       // this wave's pixel pairs (ow, ow + 1)
+      const int p = ow + half;
+      const bool pok = p < W;
+      const float d0 = (pok && c0ok) ? drow[(size_t)p * ldy] : 0.f;
+      const float d1 = (pok && c1ok) ? drow[(size_t)p * ldy + 32] : 0.f;
+      const float b = (pok && koff >= 0) ? xs[p * cin + koff] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, acc1, 0, 0, 0);
+    }
+  }
+  // sum the four waves' tiles through LDS, then one thread per (channel, column)
+  __syncthreads();
+  float* red = xs;                                   // [4][64][32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    red[(wave * 64 + row) * 32 + l31] = acc0[r];
+    red[(wave * 64 + 32 + row) * 32 + l31] = acc1[r];
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int co = e >> 5, k = e & 31;
+    if (k < ktot && co0 + co < cout)
+      partial[((size_t)blockIdx.x * cout + co0 + co) * ktot + k] =
+          (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+  }
+}
+
 // partial[s][co][(kh,kw,ci)] --sum over s--> dw[co][ci][kh][kw]
 // 16 outputs per block x 16 split lanes (the small-channel convs have few outputs and ~1000 splits: one thread per
 // output walked them serially, 235 us for 1728 outputs)
@@ -620,6 +689,21 @@ int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* worksp
   }
   float* partial = static_cast<float*>(workspace);
   hipStream_t st = as_stream(stream);
+  if (cin <= 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && g.M >= 65536 &&
+      (size_t)3 * (w + 2) * cin * sizeof(float) <= 32 * 1024) {
+    const int rows = n * h;
+    int ns = p.nsplit < rows ? p.nsplit : rows;                       // splits the workspace was sized for
+    const int rps = cdiv(rows, ns);
+    ns = cdiv(rows, rps);
+    hipLaunchKernelGGL(wgrad_smallcin_kernel, dim3(ns, cdiv(cout, 64)), dim3(256), (size_t)32 * 1024, st,
+                       x, dy, partial, n, h, w, cin, cout, ldx, ldy, rps);
+    int rc0 = check_launch("wgrad_smallcin");
+    if (rc0) return rc0;
+    long total0 = (long)cout * g.Ktot;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total0, 16)), dim3(256), 0, st, partial, dw, ns, cout, cin, kh * kw,
+                       g.Ktot);
+    return check_launch("wgrad_reduce");
+  }
   const bool va = (cout % 4 == 0) && (ldy % 4 == 0);
   const bool vb = (cin % 4 == 0) && (ldx % 4 == 0);
   int rc;
