@@ -303,3 +303,30 @@ def test_rowtap_wgrad_against_fp64(case):
         dw, db = ops.conv2d_wgrad_raw(xg, dyg, (cout, cin, 3, 3), 1, 1, True)
     assert _rel(dw, ref) < 1.5e-5
     assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
+
+
+def test_small_channel_kernels_at_full_image_size():
+    """The exact-fp32 kernels that take over at >= 65536 pixels: <= 4 destination channels (generator tail conv,
+    discriminator head dgrad) and the 3 -> 64 weight gradient; ragged 259 x 257 image so edge patches, the odd last
+    pixel pair and the zero halo are all exercised."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    n, h, w = 1, 259, 257
+    x64 = torch.randn(n, 64, h, w, generator=g)
+    w3 = torch.randn(3, 64, 3, 3, generator=g) * 0.05
+    b3 = torch.randn(3, generator=g)
+    ref = F.conv2d(x64.double(), w3.double(), b3.double(), padding=1)
+    got = ops.conv2d_fwd_raw(x64.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(w3.to(dev)), b3.to(dev), 1, 1)
+    assert _rel(got, ref) < 5e-6
+    w0 = torch.randn(64, 3, 3, 3, generator=g) * 0.1                 # head conv 3 -> 64: its dgrad has 3 destination channels
+    dy = torch.randn(n, 64, h, w, generator=g)
+    refd = torch.nn.grad.conv2d_input((n, 3, h, w), w0.double(), dy.double(), padding=1)
+    dyg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+    gotd = ops.conv2d_dgrad_raw(dyg, torch.nn.Parameter(w0.to(dev)), (n, 3, h, w), 1, 1)
+    assert _rel(gotd, refd) < 5e-6
+    x3 = torch.randn(n, 3, h, w, generator=g)
+    refw = torch.nn.grad.conv2d_weight(x3.double(), (64, 3, 3, 3), dy.double(), padding=1)
+    dw, db = ops.conv2d_wgrad_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), dyg, (64, 3, 3, 3), 1, 1, True)
+    assert _rel(dw, refw) < 5e-6
+    assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
