@@ -406,6 +406,78 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 }
 
 
+// ---- forward of 3x3 stride-1 pad-1 convs with <= 3 input channels (discriminator / VGG / generator head) ---------- //
+// K = 9*Cin <= 27 pads to 32 = sixteen 32x32x2 fp32 MFMA steps; the whole weight matrix (32 x 64) lives in registers.
+// A block takes one image row: the three input rows (zero halo) are staged in LDS, a wave owns 32 consecutive output
+// pixels x 64 channels, gathers its A values from LDS and stores 128-byte channel runs.  Write-bound by design.
+__global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ packed,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int N, int H, int W, int cin, int cout, int ldx, int ldy,
+                                                            int ldw, float slope, int flags) {
+  extern __shared__ float xs[];                      // [3][W + 2][cin]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int co0 = blockIdx.y * 64;
+  const int ktot = 9 * cin;
+  const int rowlen = (W + 2) * cin;
+  int koff[16];
+  float bw0[16], bw1[16];
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) {
+    const int k = 2 * s_ + half;
+    koff[s_] = -1;
+    bw0[s_] = bw1[s_] = 0.f;
+    if (k < ktot) {
+      const int tap = k / cin, ci = k - tap * cin;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      koff[s_] = kh * rowlen + kw * cin + ci;
+      if (co0 + l31 < cout) bw0[s_] = packed[(size_t)k * ldw + co0 + l31];
+      if (co0 + 32 + l31 < cout) bw1[s_] = packed[(size_t)k * ldw + co0 + 32 + l31];
+    }
+  }
+  float b0 = 0.f, b1 = 0.f;
+  if (flags & SRHIP_EPI_BIAS) {
+    if (co0 + l31 < cout) b0 = bias[co0 + l31];
+    if (co0 + 32 + l31 < cout) b1 = bias[co0 + 32 + l31];
+  }
+  const int r = blockIdx.x;
+  const int n = r / H, oh = r - n * H;
+  for (int e = tid; e < 3 * rowlen; e += 256) {
+    const int kh = e / rowlen, rem = e - kh * rowlen;
+    const int col = rem / cin, ci = rem - col * cin;
+    const int ih = oh + kh - 1, iw = col - 1;
+    xs[e] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[((size_t)(n * H + ih) * W + iw) * ldx + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int ow0 = wave * 32; ow0 < W; ow0 += 128) {
+    const int p = min(ow0 + l31, W - 1);             // lanes past the row end compute a duplicate, never stored
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const float a = koff[s_] >= 0 ? xs[p * cin + koff[s_]] : 0.f;
+      acc0 = mfma32(a, bw0[s_], acc0);
+      acc1 = mfma32(a, bw1[s_], acc1);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ow = ow0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (ow < W) {
+        float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
+        if (flags & SRHIP_EPI_LRELU) {
+          v0 = v0 > 0.f ? v0 : v0 * slope;
+          v1 = v1 > 0.f ? v1 : v1 * slope;
+        }
+        float* o = y + ((size_t)r * W + ow) * ldy + co0 + l31;
+        if (co0 + l31 < cout) o[0] = v0;
+        if (co0 + 32 + l31 < cout) o[32] = v1;
+      }
+    }
+  }
+}
+
 // ---- weight gradient of 3x3 stride-1 pad-1 convs with <= 3 input channels (discriminator / VGG head, 3 -> 64) ---- //
 // dW[64][27] = dy^T [64 x pixels] . xcol [pixels x 27]: with the PIXELS as the contraction the exact-fp32 MFMA
 // (32x32x2) fits well -- M = 64 channels = two tiles, N = 27 columns padded to 32 -- and costs ~40 us of matrix time
@@ -629,6 +701,12 @@ int legacy_conv2d_fwd(const float* x, const float* packed, const float* bias, co
   long M = (long)n * g.Ho * g.Wo;
   SRHIP_REQUIRE(M < (1L << 31) && (long)n * h * w < (1L << 31), "conv2d_fwd: pixel count overflows int32");
   g.M = (int)M; g.slope = slope; g.flags = flags; g.accumulate = 0;
+  if (cin <= 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && M >= 65536 &&
+      !(flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) && (size_t)3 * (w + 2) * cin * sizeof(float) <= 32 * 1024) {
+    hipLaunchKernelGGL(headconv_fwd_kernel, dim3(n * h, cdiv(cout, 64)), dim3(256), (size_t)3 * (w + 2) * cin * sizeof(float),
+                       as_stream(stream), x, packed, bias, y, n, h, w, cin, cout, ldx, ldy, g.ldw, slope, flags);
+    return check_launch("headconv_fwd");
+  }
   return run_fprop(x, packed, bias, residual, rowscale, y, g, as_stream(stream));
 }
 

@@ -330,3 +330,7 @@ def test_small_channel_kernels_at_full_image_size():
     dw, db = ops.conv2d_wgrad_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), dyg, (64, 3, 3, 3), 1, 1, True)
     assert _rel(dw, refw) < 5e-6
     assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
+    b0 = torch.randn(64, generator=g)                                  # head conv forward, bias + LeakyReLU
+    refh = F.leaky_relu(F.conv2d(x3.double(), w0.double(), b0.double(), padding=1), 0.2)
+    goth = ops.conv2d_fwd_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(w0.to(dev)), b0.to(dev), 1, 1, 0.2)
+    assert _rel(goth, refh) < 5e-6

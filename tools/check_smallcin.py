@@ -20,3 +20,12 @@ for B, h, w in ((32, 216, 216), (3, 70, 131)):
     print('B=%d %dx%d  3->64 wgrad err %.2e' % (min(B, 3), h, w, float((dw.double() - ref).abs().max() / ref.abs().max())))
     t = timeit(lambda: ops.conv2d_wgrad_raw(x, dy, (64, 3, 3, 3), 1, 1, True))
     print('   B=%d time %.3f ms' % (B, t), flush=True)
+# 3 -> 64 forward (head conv) at full size
+x = torch.randn(32, 3, 216, 216, device=dev).contiguous(memory_format=torch.channels_last)
+w0 = torch.nn.Parameter(torch.randn(64, 3, 3, 3, device=dev) * 0.1); b0 = torch.randn(64, device=dev)
+ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x[:2].double(), w0.double(), b0.double(), padding=1), 0.2)
+y = ops.conv2d_fwd_raw(x, w0, b0, 1, 1, 0.2)
+print('3->64 fwd err %.2e  time %.3f ms' % (float((y[:2].double() - ref).abs().max() / ref.abs().max()), timeit(lambda: ops.conv2d_fwd_raw(x, w0, b0, 1, 1, 0.2))))
+xr = torch.randn(2, 3, 259, 257, device=dev).contiguous(memory_format=torch.channels_last)
+ref = torch.nn.functional.conv2d(xr.double(), w0.double(), None, padding=1)
+print('ragged err %.2e' % float((ops.conv2d_fwd_raw(xr, w0, None, 1, 1).double() - ref).abs().max() / ref.abs().max()))
