@@ -199,6 +199,22 @@ int srhip_ssim_u8(const float* a, const float* b, double* partial, int n, int h,
 int srhip_adam_step(float* p, const float* g, float* m, float* v, float* state, long n, float lr, float b1,
                     float b2, float eps, float grad_scale, float clip, void* stream);
 
+/* ---- input pipeline ------------------------------------------------------ *
+ * Pillow-compatible resampling of uint8 NHWC tiles, replacing the per-sample PIL calls of
+ * RGB_TrainDatasetFromFolder.__getitem__ (data/dataset.py:428 lr = resize(img, BICUBIC), :435 bc = resize(lr, BICUBIC))
+ * and the test-time Resize (data/data.py:331, BILINEAR).  Bit-exact with Image.resize for 8-bit images
+ * (Pillow Resample.c arithmetic: 22-bit fixed-point weights, clip after each pass, horizontal pass first).
+ * srhip_resample_ksize / srhip_resample_coeffs are host-only (weights per output coordinate, computed in double);
+ * srhip_resample_pass_u8 runs one pass (axis 1: width, axis 0: height) with device copies of bounds/coeffs;
+ * srhip_u8_to_float is torchvision's to_tensor scaling (value / 255 in fp32).                    */
+#define SRHIP_FILTER_BILINEAR 2
+#define SRHIP_FILTER_BICUBIC 3
+int srhip_resample_ksize(int in_size, int out_size, int filter);
+int srhip_resample_coeffs(int in_size, int out_size, int filter, int* bounds, int* coeffs);
+int srhip_resample_pass_u8(const unsigned char* src, unsigned char* dst, const int* bounds_dev, const int* coeffs_dev,
+                           int ksize, int n, int h, int w, int c, int axis, int out_size, void* stream);
+int srhip_u8_to_float(const unsigned char* src, float* dst, long count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

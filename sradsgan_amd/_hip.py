@@ -18,6 +18,10 @@ SIGNATURES = {
     'srhip_debug_set': (_i, [_i, _i]),
     'srhip_set_conv_math': (_i, [_i]),
     'srhip_get_conv_math': (_i, []),
+    'srhip_resample_ksize': (_i, [_i, _i, _i]),
+    'srhip_resample_coeffs': (_i, [_i, _i, _i, _vp, _vp]),
+    'srhip_resample_pass_u8': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'srhip_u8_to_float': (_i, [_vp, _vp, _l, _vp]),
     'srhip_packed_elems': (_sz, [_i] * 5),
     'srhip_pack_entry_bytes': (_i, []),
     'srhip_packed_is_fast': (_i, [_i] * 5),
