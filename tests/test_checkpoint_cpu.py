@@ -1,0 +1,84 @@
+"""Checkpoint / chain-training host logic (sradsgan_amd/checkpoint.py) on CPU: file format the reference reads, the
+shape-aware partial load between scales, and the plateau rule of sradsgan.py:985-1036 replayed step by step."""
+import os
+
+import torch
+
+from oracle import sradsgan_ref as O
+from sradsgan_amd import checkpoint as C
+from sradsgan_amd import model as M
+
+
+def _gen(scale, groups=2, blocks=1, mod=M):
+    return mod.GeneratorResNet(mod.ResGroup, n_residual_blocks=groups, n_basic_blocks=blocks, upscale_factor=scale)
+
+
+def test_epoch_files_round_trip_and_load_in_the_reference_layout(tmp_path):
+    g = _gen(4)
+    O.det_init_(g, prefix='G.')
+    path = C.save_epoch_network(str(tmp_path), g, 'generator', 7)
+    assert os.path.basename(path) == 'generator_param_epoch_7.pkl'
+    raw = torch.load(path)                               # what the reference's load_epoch_network would read
+    assert isinstance(raw, dict) and all(isinstance(v, torch.Tensor) and v.device.type == 'cpu' for v in raw.values())
+    ref = _gen(4, mod=O)                                 # the oracle's generator carries the reference's key set
+    ref.load_state_dict(raw, strict=True)
+    g2 = _gen(4)
+    C.load_epoch_network(path, g2, strict=True)
+    for (k, a), (_, b) in zip(g.state_dict().items(), g2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert g2.GAB_UP.upsampling[0].weight is g2.GAB_UP.upsampling[3].weight       # tied stages stay tied after loading
+
+
+def test_save_model_and_load_model(tmp_path):
+    g, d = _gen(2), M.Discriminator()
+    C.save_model(str(tmp_path), g, d)
+    C.save_model(str(tmp_path), g, d, epoch=3)
+    names = sorted(os.listdir(os.path.join(str(tmp_path), 'model')))
+    assert names == ['discriminator_param.pkl', 'discriminator_param_epoch_3.pkl', 'generator_param.pkl', 'generator_param_epoch_3.pkl']
+    g2 = _gen(2)
+    assert C.load_model(str(tmp_path), g2) is True
+    assert C.load_model(str(tmp_path / 'nothing'), g2) is False
+
+
+def test_chain_training_partial_load_between_scales():
+    x2 = _gen(2)
+    O.det_init_(x2, prefix='G.')
+    x4, x3 = _gen(4), _gen(3)
+    loaded, missing, mismatch, unused = C.load_compatible(x4, x2.state_dict())
+    assert not mismatch and not unused                   # x2 -> x4: same upsampler conv, one more (tied) stage
+    assert sorted(missing) == ['GAB_UP.upsampling.3.bias', 'GAB_UP.upsampling.3.weight']
+    assert torch.equal(x4.conv1[0].weight, x2.conv1[0].weight)
+    assert torch.equal(x4.GAB_UP.upsampling[3].weight, x2.GAB_UP.upsampling[0].weight)   # tied: filled through stage 0
+    loaded, missing, mismatch, unused = C.load_compatible(x3, x2.state_dict())
+    assert sorted(mismatch) == ['GAB_UP.upsampling.0.bias', 'GAB_UP.upsampling.0.weight']   # 64 -> 256 vs 64 -> 576
+    assert not missing and not unused and len(loaded) == len(x3.state_dict()) - 2
+    assert torch.equal(x3.res_groups[1].conv.weight, x2.res_groups[1].conv.weight)
+
+
+class _Lr:
+    lr_G = 2e-4
+    lr_D = 2e-4
+
+
+def test_plateau_rule_replays_the_reference_sequence():
+    ctl, step, reloaded = C.PlateauRollback(lr=2e-4), _Lr(), []
+    epoch = 0
+    # epochs 0..2 improve (psnr; then ssim only; then ergas only); epoch 3 still counts as an improvement because the
+    # reference initialises lpips_max to 10000 and only the branch taken updates its own maximum (:985-1003); then five
+    # epochs without any improvement
+    seq = [(30.0, 0.80, 5.0, 0.5), (29.0, 0.81, 5.0, 0.5), (29.0, 0.80, 4.0, 0.5)] + [(28.0, 0.70, 6.0, 0.6)] * 6
+    for i, m in enumerate(seq):
+        epoch, rb = ctl.update(epoch, *m, step=step, on_rollback=reloaded.append)
+        if i < 8:
+            assert not rb and epoch == i + 1
+    assert ctl.best_step == 3
+    assert rb and reloaded == [4] and epoch == 4          # best epoch index 3 -> generator_param_epoch_4.pkl, resume at 4
+    assert step.lr_G == 1e-4 and step.lr_D == 2e-4 and ctl.lr == 1e-4   # D halves only once lr < 1e-4 (checked before halving)
+    assert len(ctl.history) == 4 and ctl.no_improve == 0
+    for m in [(28.0, 0.70, 6.0, 0.6)] * 5:
+        epoch, rb = ctl.update(epoch, *m, step=step)
+    assert rb and step.lr_G == 5e-5 and step.lr_D == 2e-4 and ctl.lr == 5e-5
+    for m in [(28.0, 0.70, 6.0, 0.6)] * 5:
+        epoch, rb = ctl.update(epoch, *m, step=step)
+    assert rb and step.lr_D == 1e-4                       # now lr (5e-5) < 1e-4
+    assert ctl.keep_training(3, 100) and not C.PlateauRollback(lr=5e-6).keep_training(0, 100)

@@ -281,3 +281,31 @@ def test_graphed_evaluator_matches_eager_across_replays():
         assert torch.equal(got['recon'], want['recon']), it
         for k in ('mse', 'psnr', 'ssim', 'ergas'):
             assert torch.equal(got['sr'][k], want['sr'][k]), (it, k)
+
+
+def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
+    """Weights (reference file format) + optimiser state saved after step 1 and loaded into a fresh trainer give the
+    same step 2 as the uninterrupted run: arena views survive load_state_dict, packed weights are refreshed."""
+    from sradsgan_amd import checkpoint as C
+    from sradsgan_amd.train_step import TrainStep
+
+    def make():
+        (g, d, f), _ = build_pair(2, 1, 4, DEV)
+        return g, d, f, TrainStep(g, d, f)
+    gen = torch.Generator().manual_seed(9)
+    batches = [(torch.rand(2, 3, 8, 8, generator=gen).to(DEV), torch.rand(2, 3, 32, 32, generator=gen).to(DEV),
+                torch.rand(2, 1, 1, 1, generator=gen).to(DEV)) for _ in range(2)]
+    g, d, f, step = make()
+    step(*batches[0])
+    C.save_epoch_network(str(tmp_path), g, 'generator', 1)
+    C.save_epoch_network(str(tmp_path), d, 'discriminator', 1)
+    C.save_optimizer_state(str(tmp_path / 'opt.pt'), step)
+    want = {k: float(v) for k, v in step(*batches[1]).items() if k != 'gen_hr'}
+    g2, d2, f2, step2 = make()
+    C.load_epoch_network(C.epoch_path(str(tmp_path), 'generator', 1), g2)
+    C.load_epoch_network(C.epoch_path(str(tmp_path), 'discriminator', 1), d2)
+    C.load_optimizer_state(str(tmp_path / 'opt.pt'), step2)
+    assert step2.arena_G.check_views() and step2.arena_D.check_views()
+    got = {k: float(v) for k, v in step2(*batches[1]).items() if k != 'gen_hr'}
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
