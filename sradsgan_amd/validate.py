@@ -90,3 +90,31 @@ class GraphedEvaluator:
             static['bicubic'].copy_(bicubic)
         graph.replay()
         return out
+
+
+def format_results(mode, rlt):
+    """The log line of the reference's PrintLogger.print_format_results (SRADSGAN/utils/logger.py:117-147), as a
+    string: '<epoch:  3, iter:   1,200, time:1.25, lr:2.0e-04> dataset: AID key: 1.23e-04 ...' -- '{:.2e}' per value
+    in 'train' mode, '{:.4e}' in 'val' mode.  `rlt` must carry epoch, iters, time, model (and optionally lr); it is
+    not modified."""
+    rlt = dict(rlt)
+    epoch, iters, time_, model = rlt.pop('epoch'), rlt.pop('iters'), rlt.pop('time'), rlt.pop('model')
+    if 'lr' in rlt:
+        message = '<epoch:{:3d}, iter:{:8,d}, time:{:.2f}, lr:{:.1e}> '.format(epoch, iters, time_, rlt.pop('lr'))
+    else:
+        message = '<epoch:{:3d}, iter:{:8,d}, time:{:.2f}> '.format(epoch, iters, time_)
+    message += '{:s}: {:s} '.format('dataset', model)
+    for label, value in rlt.items():
+        if mode == 'train':
+            message += '{:s}: {:.2e} '.format(label, value)
+        elif mode == 'val':
+            message += '{:s}: {:.4e} '.format(label, value)
+    return message
+
+
+def append_log(path, mode, rlt):
+    """Appends format_results(mode, rlt) to loss_log.txt / val_log.txt like the reference (logger.py:142-147)."""
+    line = format_results(mode, rlt)
+    with open(path, 'a') as f:
+        f.write(line + '\n')
+    return line

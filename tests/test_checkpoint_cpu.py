@@ -82,3 +82,18 @@ def test_plateau_rule_replays_the_reference_sequence():
         epoch, rb = ctl.update(epoch, *m, step=step)
     assert rb and step.lr_D == 1e-4                       # now lr (5e-5) < 1e-4
     assert ctl.keep_training(3, 100) and not C.PlateauRollback(lr=5e-6).keep_training(0, 100)
+
+
+def test_val_log_line_format(tmp_path):
+    """logger.py:117-147: field order, thousands separator, precision per mode."""
+    from sradsgan_amd import validate
+    rlt = dict(epoch=3, iters=1200, time=1.2549, model='AID', lr=2e-4, bicubic_psnr=27.123456, srwgan_psnr=29.5)
+    assert validate.format_results('val', rlt) == \
+        '<epoch:  3, iter:   1,200, time:1.25, lr:2.0e-04> dataset: AID bicubic_psnr: 2.7123e+01 srwgan_psnr: 2.9500e+01 '
+    del rlt['lr']
+    assert validate.format_results('train', rlt) == \
+        '<epoch:  3, iter:   1,200, time:1.25> dataset: AID bicubic_psnr: 2.71e+01 srwgan_psnr: 2.95e+01 '
+    p = tmp_path / 'val_log.txt'
+    validate.append_log(str(p), 'val', rlt)
+    validate.append_log(str(p), 'val', rlt)
+    assert p.read_text().count('\n') == 2 and 'epoch' in rlt
