@@ -1,0 +1,49 @@
+"""The reference's trainer surface on the HIP path (sradsgan_amd/trainer.py): two tiny epochs end to end."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _loaders():
+    g = torch.Generator().manual_seed(21)
+    train = [torch.randint(0, 256, (2, 32, 32, 3), generator=g, dtype=torch.uint8) for _ in range(2)]       # uint8 HR tiles
+    hr = torch.rand(2, 3, 32, 32, generator=g)
+    test = [(torch.nn.functional.avg_pool2d(hr, 4), hr, hr.clamp(0, 1), ['a', 'b'])]                          # reference-style tuple
+    return train, test
+
+
+def test_train_validate_and_checkpoints_end_to_end(tmp_path):
+    from sradsgan_amd import trainer as T
+    train, test = _loaders()
+    args = T.default_args(scale_factor=4, num_epochs=2, batch_size=2, save_dir=str(tmp_path), crop_size=32, hr_height=32,
+                          hr_width=32, sample_interval=1, n_residual_blocks=1, n_basic_blocks=1)
+    assert args.lr == 0.0002 and args.lambda_gp == 10 and args.weight_gan == 1e-3          # reference defaults survive
+    net = T.SRADSGAN(args, train_loader=train, test_loader=test)
+    hist = net.train()
+    assert len(hist) == 2 and all(torch.isfinite(torch.tensor([h['loss_G'], h['loss_D'], h['psnr'], h['ssim'], h['ergas']])).all() for h in hist)
+    files = sorted(os.listdir(os.path.join(str(tmp_path), 'model')))
+    assert files == ['discriminator_param.pkl', 'discriminator_param_epoch_1.pkl', 'discriminator_param_epoch_2.pkl',
+                     'generator_param.pkl', 'generator_param_epoch_1.pkl', 'generator_param_epoch_2.pkl']
+    val_lines = open(os.path.join(str(tmp_path), 'val_log.txt')).read().strip().splitlines()
+    assert len(val_lines) == 2 and val_lines[0].startswith('<epoch:  0, iter:       0, time:') and 'srcnn_psnr:' in val_lines[0]
+    assert 'loss_G:' in open(os.path.join(str(tmp_path), 'loss_log.txt')).read()
+    # mfeNew_validate on the saved final generator reproduces the last in-training validation
+    psnr, ssim, ergas, lpips = net.mfeNew_validate(epoch=2, modelpath=os.path.join(str(tmp_path), 'model', 'generator_param_epoch_2.pkl'))
+    assert abs(psnr - hist[-1]['psnr']) < 1e-9 and abs(ssim - hist[-1]['ssim']) < 1e-12 and lpips != lpips
+    assert 'sradsgan_psnr:' in open(os.path.join(str(tmp_path), 'val_log.txt')).read().splitlines()[-1]
+    # resume path: epoch != 0 loads the epoch files strictly (sradsgan.py:705-711)
+    args2 = T.default_args(**dict(vars(args), epoch=2, num_epochs=2))
+    net2 = T.SRADSGAN(args2, train_loader=train, test_loader=test)
+    net2._build()
+    for (k, a), (_, b) in zip(net.generator.state_dict().items(), net2.generator.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+
+
+def test_unsupported_reference_options_fail_loudly():
+    from sradsgan_amd import trainer as T
+    with pytest.raises(NotImplementedError):
+        T.SRADSGAN(T.default_args(penalty_type='hinge'))
