@@ -13,6 +13,7 @@ all-reduce of G and D gradients).  Inputs are resident in HBM before the timed r
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, fp32 MFMA) timed with HIP
                   events on the launch stream: algorithmic FLOPs per launch / average duration;
+  exact_fp32_mode -- the same job re-timed (4 steps) with the conv contraction in exact fp32 (DESIGN.md section 3);
   cpu_baseline -- the CPU oracle (oracle/sradsgan_ref.py, a port of the reference step) timed on the
                   host cores of this box on a bounded sample (rank 0, N=1 only).
 """
@@ -54,6 +55,7 @@ def parse():
     ap.add_argument('--conv-math', choices=('fp32', 'bf16x3'), default=None,
                     help="arithmetic of the conv contraction: fp32 MFMA, or split-bf16 x3 MFMA with fp32 accumulate "
                          "(default: the library default, sradsgan_amd/_hip.py DEFAULT_CONV_MATH)")
+    ap.add_argument('--no-fp32-line', action='store_true', help='skip the short extra run in exact-fp32 conv arithmetic')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--workload', choices=['train', 'infer'], default='train',
@@ -331,6 +333,27 @@ def main():
     losses = {k: float(out[k]) for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')}
     finite = all(v == v and abs(v) != float('inf') for v in losses.values())
 
+    # The same job with the conv contraction in exact fp32 (a short extra run after the timed region, every rank takes
+    # part): reported next to the headline so both arithmetic modes are in one line
+    alt = None
+    if conv_math == 'bf16x3' and not args.no_fp32_line:
+        ops.set_conv_math('fp32')
+        for _ in range(2):
+            step(lr, hr, alpha)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            step(lr, hr, alpha)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        ops.set_conv_math('bf16x3')
+        if world > 1:
+            t = torch.tensor([dt1], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t.item())
+        alt = {'conv_math': 'fp32', 'value': round(world * B * 4 / dt1, 3), 'ms_per_step': round(dt1 / 4 * 1e3, 3), 'steps': 4,
+               'step_frac_of_mfma_peak': round(world * B * 4 / dt1 * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -347,6 +370,8 @@ def main():
             'step_frac_of_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (MATH_PEAK[conv_math][0] * world), 4),
         }
         line['config']['conv_math'] = conv_math
+        if alt is not None:
+            line['exact_fp32_mode'] = alt
         line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
