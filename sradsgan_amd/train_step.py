@@ -53,6 +53,7 @@ class TrainStep:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = self.arena_G.flat_p.device
         self._wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda') else None
+        self._d_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._calls = 0
@@ -164,15 +165,17 @@ class TrainStep:
             # BEFORE the generator's backward so the two chains run concurrently on the GPU.  autograd replays every
             # node on the stream of its forward, so their double backward stays on the side stream too.
             main = torch.cuda.current_stream()
-            side.wait_stream(main)                                # gen_hr, d_gen and running-stat update #1 are in
-            with torch.cuda.stream(side):
+            dside = self._d_stream if self._d_stream is not None else side   # third stream: the D passes beside G's dgrads (main) and the wgrads (side)
+            dside.wait_stream(main)                               # gen_hr, d_gen and running-stat update #1 are in
+            with torch.cuda.stream(dside):
                 loss_D, gp, total, fake = d_forward()
             for t in (gen_hr, d_gen, alpha):
-                t.record_stream(side)
+                t.record_stream(dside)
             with ops.backward_scope(skip_params=d_params):        # no discriminator wgrads in the G step (:857 -> :865)
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
             with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
                 torch.autograd.backward(total, inputs=d_params)
+            main.wait_stream(dside)
             main.wait_stream(side)
             for t in (loss_D, gp):
                 t.record_stream(main)
