@@ -58,7 +58,7 @@ def parse():
     ap.add_argument('--no-fp32-line', action='store_true', help='skip the short extra run in exact-fp32 conv arithmetic')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--workload', choices=['train', 'infer'], default='train',
+    ap.add_argument('--workload', choices=['train', 'infer', 'srgan', 'edsr'], default='train',
                     help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]; not the headline line)")
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
@@ -232,6 +232,61 @@ def run_inference(args, device):
                       'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
 
 
+def run_sibling(args, device):
+    """SURVEY 8(f) rank 4, N=1 only: `srgan` = one SRGAN training iteration (srgan.py:335-365; 16 residual blocks, D, VGG
+    features) on BASELINE's tile shape (x4, LR 54x54 -> HR 216x216, batch 32); `edsr` = one EDSR L1 training iteration of
+    BASELINE configs[0]'s network (Net(3, 256, 32, 2), LR 108x108 -> HR 216x216, batch 4) with torch's Adam."""
+    import torch
+    from sradsgan_amd import ops
+    gen = torch.Generator().manual_seed(4321)
+    if args.workload == 'srgan':
+        from sradsgan_amd.model import srgan as M
+        B = args.batch
+        torch.manual_seed(20240)
+        G, D, Fx = M.GeneratorResNet(3, 3, 16, SCALE), M.Discriminator(), M.FeatureExtractor()
+        G.apply(M.weights_init_normal), D.apply(M.weights_init_normal)
+        for m in (G, D, Fx):
+            m.to(device)
+        for p in Fx.parameters():
+            p.requires_grad_(False)
+        ops.mark_static(Fx)
+        oG = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.9, 0.999))
+        oD = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.9, 0.999))
+        hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
+        lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
+        run = lambda: M.train_step(G, D, Fx, oG, oD, lr, hr)['loss_G']
+        name = 'SRGAN x4 training step (G 16 blocks + D + VGG features, LSGAN), LR 54x54 -> HR 216x216, batch %d' % B
+    else:
+        from sradsgan_amd.model import edsr as M
+        B = 4 if args.batch == PER_GPU_BATCH else args.batch
+        torch.manual_seed(20240)
+        net = M.Net(3, 256, 32, 2).to(device)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        hr = torch.rand(B, 3, 216, 216, generator=gen).to(device)
+        lr = torch.rand(B, 3, 108, 108, generator=gen).to(device)
+
+        def run():
+            opt.zero_grad(set_to_none=True)
+            loss = (net(lr) - hr).abs().mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        name = 'EDSR x2 L1 training step (Net(3,256,32,2), BASELINE configs[0]), LR 108x108 -> HR 216x216, batch %d' % B
+    for _ in range(args.warmup):
+        out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({'metric': 'training images/sec (216x216 HR tiles)', 'value': round(B * args.steps / dt, 2),
+                      'unit': 'img/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'dtype': 'f32',
+                      'data': 'synthetic', 'config': {'workload': name, 'conv_math': ops.get_conv_math()},
+                      'last_loss': round(float(out), 6)}), flush=True)
+
+
 def cpu_baseline_subprocess(iters, timeout_s=240):
     """Runs the CPU leg in a child process (own thread pool, hard wall-clock bound) and returns its dict."""
     import subprocess
@@ -287,6 +342,9 @@ def main():
         return
     if args.workload == 'infer':
         run_inference(args, device)
+        return
+    if args.workload in ('srgan', 'edsr'):
+        run_sibling(args, device)
         return
     from sradsgan_amd.train_step import TrainStep
     from sradsgan_amd import dp

@@ -808,7 +808,13 @@ def batch_norm_act(x, bn, slope=None):
     """Train-mode BatchNorm2d + LeakyReLU (sradsgan.py:478-479) on the fused HIP kernels; updates the
     running statistics like nn.BatchNorm2d (momentum 0.1, unbiased running_var).  Twice differentiable."""
     if not bn.training:
-        raise NotImplementedError('the reference never puts the discriminator in eval() (SURVEY a11)')
+        # eval(): running statistics, a per-channel affine (SRGAN's generator at validation time; the SRADSGAN
+        # discriminator is never put in eval(), SURVEY a11)
+        _require_gpu(x, 'batch_norm')
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        y = nhwc(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        return y if slope is None else torch.nn.functional.leaky_relu(y, float(slope))
     y = _BNTrainFwd.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
     with torch.no_grad():
         bn.num_batches_tracked += 1
