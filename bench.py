@@ -58,7 +58,7 @@ def parse():
     ap.add_argument('--no-fp32-line', action='store_true', help='skip the short extra run in exact-fp32 conv arithmetic')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--workload', choices=['train', 'infer', 'srgan', 'edsr'], default='train',
+    ap.add_argument('--workload', choices=['train', 'infer', 'srgan', 'sragan', 'edsr'], default='train',
                     help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]; not the headline line)")
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
@@ -233,7 +233,8 @@ def run_inference(args, device):
 
 
 def run_sibling(args, device):
-    """SURVEY 8(f) rank 4, N=1 only: `srgan` = one SRGAN training iteration (srgan.py:335-365; 16 residual blocks, D, VGG
+    """SURVEY 8(f) rank 4, N=1 only: `sragan` = one SRAGAN training iteration (TrainStep around the SRAGAN generator);
+    `srgan` = one SRGAN training iteration (srgan.py:335-365; 16 residual blocks, D, VGG
     features) on BASELINE's tile shape (x4, LR 54x54 -> HR 216x216, batch 32); `edsr` = one EDSR L1 training iteration of
     BASELINE configs[0]'s network (Net(3, 256, 32, 2), LR 108x108 -> HR 216x216, batch 4) with torch's Adam."""
     import torch
@@ -256,6 +257,29 @@ def run_sibling(args, device):
         lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
         run = lambda: M.train_step(G, D, Fx, oG, oD, lr, hr)['loss_G']
         name = 'SRGAN x4 training step (G 16 blocks + D + VGG features, LSGAN), LR 54x54 -> HR 216x216, batch %d' % B
+    elif args.workload == 'sragan':
+        # SRAGAN's iteration is SRADSGAN's (sragan.py:539-575) around its own generator (12 residual blocks x 5 basic
+        # blocks, sragan.py:465-467): the same TrainStep
+        from sradsgan_amd.model import sragan as M
+        from sradsgan_amd.train_step import TrainStep
+        from sradsgan_amd.trainer import weights_init_normal
+        B = args.batch
+        torch.manual_seed(20240)
+        G = M.GeneratorResNet(M.ResidualBlock_Block_WithAttention, n_residual_blocks=12, n_basic_blocks=5,
+                              upscale_factor=SCALE)
+        D, Fx = M.Discriminator(), M.FeatureExtractor()
+        G.apply(weights_init_normal), D.apply(weights_init_normal)
+        with torch.no_grad():
+            G.ca.gamma.fill_(0.5), G.sa.gamma.fill_(0.5)            # attention paths live, as in the main bench
+        for m in (G, D, Fx):
+            m.to(device)
+        step = TrainStep(G, D, Fx)
+        hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
+        lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
+        alpha = torch.rand(B, 1, 1, 1, generator=gen).to(device)
+        run = lambda: step(lr, hr, alpha)['loss_G']
+        name = ('SRAGAN x4 training step (G 12x5 attention blocks + D + VGG features, WGAN-GP), LR 54x54 -> HR 216x216, '
+                'batch %d' % B)
     else:
         from sradsgan_amd.model import edsr as M
         B = 4 if args.batch == PER_GPU_BATCH else args.batch
@@ -343,7 +367,7 @@ def main():
     if args.workload == 'infer':
         run_inference(args, device)
         return
-    if args.workload in ('srgan', 'edsr'):
+    if args.workload in ('srgan', 'sragan', 'edsr'):
         run_sibling(args, device)
         return
     from sradsgan_amd.train_step import TrainStep
