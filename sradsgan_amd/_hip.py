@@ -84,6 +84,10 @@ def lib():
         if mode not in ('fp32', 'bf16x3'):
             raise HipLibraryError("SRADSGAN_CONV_MATH must be 'fp32' or 'bf16x3', got %r" % mode)
         handle.srhip_set_conv_math(1 if mode == 'bf16x3' else 0)
+        for item in os.environ.get('SRHIP_DEBUG', '').split(','):      # experiment knobs, "key:value,..." (sradsgan_hip.h)
+            if item:
+                key, value = item.split(':')
+                handle.srhip_debug_set(int(key), int(value))
         _lib = handle
     return _lib
 

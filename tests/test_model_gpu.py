@@ -167,6 +167,19 @@ def test_train_two_iterations_small(golden):
     assert worst < TOL and wdiff < 5e-3, (worst, wdiff)
 
 
+@pytest.mark.parametrize('scale,lr_side', [(2, 16), (3, 12), (8, 4), (9, 4)])
+def test_train_two_iterations_other_scales(scale, lr_side):
+    """BASELINE configs[4]'s other factors (x2 / x3 / x8 / x9: one, one, three and two up-sampler stages, r = 2 or 3,
+    tied stage weights): two full iterations against the oracle's on identical weights and inputs."""
+    from tests.parity_util import well_conditioned_tag
+    # the input is picked by an oracle-only criterion (parity_util.well_conditioned_tag): at these tile sizes the
+    # deepest discriminator BatchNorms normalise over 8 samples and a LeakyReLU input within ~1e-5 of zero there makes
+    # the gradient comparison a coin flip between any two fp32 implementations
+    tag = well_conditioned_tag('train_x%d' % scale, 1, 2, 2, lr_side, scale)
+    worst, wdiff = train_parity(DEV, tag, 1, 2, 2, lr_side, scale, 2, None, fp64_ref=True)
+    assert worst < TOL and wdiff < 5e-3, (worst, wdiff)
+
+
 def test_train_two_iterations_full_size(golden):
     """x4, 54->216, 12 groups x 3 RAB, B=2: losses/PSNR-relevant scalars within 1e-3 of the reference; gradients of
     the first iteration scored against an fp64 evaluation of the same graph (parity_util.train_parity, fp64_ref)."""
