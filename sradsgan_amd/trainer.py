@@ -157,8 +157,9 @@ class SRADSGAN(object):
         return history
 
     # ------------------------------------------------------------------ validation -------------- #
-    def _evaluate_loader(self, generator, label):
-        if self.test_loader is None:
+    def _evaluate_loader(self, generator, label, loader=None, totals=None):
+        loader = self.test_loader if loader is None else loader
+        if loader is None:
             raise ValueError('SRADSGAN.validate: inject test_loader')
         sums = {k: 0.0 for k in ('bicubic_mse', 'bicubic_psnr', 'bicubic_ssim', 'bicubic_ergas', label + '_mse', label + '_psnr',
                                  label + '_ssim', label + '_ergas')}
@@ -166,7 +167,7 @@ class SRADSGAN(object):
         was_training = generator.training
         generator.eval()                                                                         # :1288
         start = time.time()
-        for item in self.test_loader:
+        for item in loader:
             imgs_lr, imgs_hr, imgs_bc = self._batch(item)
             out = sval.evaluate(generator, imgs_lr, imgs_hr, self.scale_factor, bicubic=imgs_bc)
             img_num += imgs_hr.size(0)
@@ -174,11 +175,15 @@ class SRADSGAN(object):
                 sums['bicubic_' + k] += float(out['bicubic'][k].sum())
                 sums[label + '_' + k] += float(out['sr'][k].sum())
         generator.train(was_training)
+        if totals is not None:                                                                   # running sums over classes
+            totals['num'] = totals.get('num', 0) + img_num
+            for k, v in sums.items():
+                totals[k] = totals.get(k, 0.0) + v
         avg = {k: v / max(img_num, 1) for k, v in sums.items()}                                 # :1365-1374
         return avg, time.time() - start
 
-    def _log_val(self, epoch, avg, elapsed, label):
-        rlt = OrderedDict(model=self.model_name, epoch=epoch, iters=epoch, time=elapsed)
+    def _log_val(self, epoch, avg, elapsed, label, model=None):
+        rlt = OrderedDict(model=self.model_name if model is None else model, epoch=epoch, iters=epoch, time=elapsed)
         for prefix in ('bicubic', label):                                                        # :1377-1390 key order
             for k in ('mse', 'psnr', 'ssim', 'ergas'):
                 rlt['%s_%s' % (prefix, k)] = avg['%s_%s' % (prefix, k)]
@@ -205,6 +210,59 @@ class SRADSGAN(object):
         avg, elapsed = self._evaluate_loader(self.generator, 'sradsgan')
         self._log_val(epoch, avg, elapsed, 'sradsgan')
         return avg['sradsgan_psnr'], avg['sradsgan_ssim'], avg['sradsgan_ergas'], float('nan')
+
+    def mfeNew_validateByClass(self, epoch, save_img=False, modelpath=None):
+        """sradsgan.py:1393-1601: the validation of mfeNew_validate once per class folder of the test set, one
+        `val_log.txt` line per class (model = class name) and a final "Total" line over all images.  The reference
+        builds one DataLoader per UCMerced class directory (:1433-1447); here `self.class_loaders` (an ordered mapping
+        class name -> iterable of batches) is injected like the other loaders.  Returns {class or 'Total': averages}."""
+        loaders = getattr(self, 'class_loaders', None)
+        if not loaders:
+            raise ValueError('SRADSGAN.mfeNew_validateByClass: inject class_loaders (class name -> loader)')
+        self.generator = self._new_generator().to(self.device)
+        if modelpath is not None:
+            self.generator.load_state_dict(torch.load(modelpath, map_location='cpu'), strict=False)   # :1400-1401
+            ckpt._after_load()
+        start, totals, result = time.time(), {}, OrderedDict()
+        for name, loader in loaders.items():
+            avg, _ = self._evaluate_loader(self.generator, 'sradsgan', loader=loader, totals=totals)
+            self._log_val(epoch, avg, time.time() - start, 'sradsgan', model=name)              # :1548-1564
+            result[name] = avg
+        num = max(totals.pop('num', 0), 1)
+        result['Total'] = {k: v / num for k, v in totals.items()}                               # :1568-1577
+        self._log_val(epoch, result['Total'], time.time() - start, 'sradsgan', model='Total')
+        return result
+
+    def mfe_test_single(self, img_fn, modelpath=None):
+        """sradsgan.py:1603-1641: centre-crop `test_crop_size` of one image file, super-resolve it, and write
+        `SR_SRADSGAN_<name>` and `SR_Bicubic_<name>` into save_dir with save_img1's quantisation (x255, clamp, truncate;
+        utils/utils.py:169-187).  The bicubic image is img_interp's (utils.py:755-780: uint8 via ToPILImage, Pillow
+        bicubic) on the device.  The comparison figure (matplotlib) is not drawn.  Returns the two uint8 HWC arrays."""
+        from PIL import Image
+        import numpy as np
+        self.generator = self._new_generator().to(self.device)
+        if modelpath is not None:
+            self.generator.load_state_dict(torch.load(modelpath, map_location='cpu'), strict=False)   # :1609-1610
+            ckpt._after_load()
+        self.generator.eval()
+        img = Image.open(img_fn).convert('RGB')
+        c = self.test_crop_size
+        left, top = int(round((img.width - c) / 2.0)), int(round((img.height - c) / 2.0))          # transforms.CenterCrop
+        u8 = torch.from_numpy(np.asarray(img.crop((left, top, left + c, top + c)), dtype=np.uint8).copy())
+        u8 = u8.unsqueeze(0).contiguous().to(self.device)                                        # [1,c,c,3] uint8
+        x = sdata.to_tensor(u8)
+        with torch.no_grad():
+            sr = self.generator(x)
+        bc_u8 = sdata.resize_u8(u8, c * self.scale_factor, c * self.scale_factor, 'bicubic')[0]  # [H,W,3]
+        sr_u8 = (sr[0] * 255.0).clamp(0, 255).to(torch.uint8).permute(1, 2, 0)                   # save_img1
+        os.makedirs(self.save_dir, exist_ok=True)
+        name = os.path.basename(img_fn)
+        out = []
+        for tag, t in (('SRADSGAN', sr_u8), ('Bicubic', bc_u8)):
+            arr = t.contiguous().cpu().numpy()
+            Image.fromarray(arr).save(os.path.join(self.save_dir, 'SR_%s_%s' % (tag, name)))
+            out.append(arr)
+        return tuple(out)
 
     # ------------------------------------------------------------------ checkpoints ------------- #
     def save_epoch_network(self, save_dir, network, network_label, iter_label):

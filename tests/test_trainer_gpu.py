@@ -43,6 +43,54 @@ def test_train_validate_and_checkpoints_end_to_end(tmp_path):
         assert torch.equal(a.cpu(), b.cpu()), k
 
 
+def test_validate_by_class_and_single_image(tmp_path):
+    """mfeNew_validateByClass (sradsgan.py:1393-1601): per-class and Total lines, Total = image-weighted mean of the
+    classes; mfe_test_single (:1603-1641): the written PNGs hold save_img1's quantisation of the generator output and
+    Pillow's own bicubic of the crop."""
+    import numpy as np
+    from collections import OrderedDict
+    from PIL import Image
+    from sradsgan_amd import trainer as T
+    g = torch.Generator().manual_seed(5)
+
+    def loader(n_batches):
+        out = []
+        for _ in range(n_batches):
+            hr = torch.rand(2, 3, 32, 32, generator=g)
+            out.append((torch.nn.functional.avg_pool2d(hr, 4), hr, hr.clamp(0, 1), ['x', 'y']))
+        return out
+    args = T.default_args(scale_factor=4, save_dir=str(tmp_path), crop_size=32, hr_height=32, hr_width=32, test_crop_size=12,
+                          n_residual_blocks=1, n_basic_blocks=1)
+    net = T.SRADSGAN(args)
+    torch.manual_seed(3)
+    gen = net._new_generator()
+    gen.apply(T.weights_init_normal)
+    path = os.path.join(str(tmp_path), 'g.pkl')
+    torch.save(gen.state_dict(), path)
+    net.class_loaders = OrderedDict([('airplane', loader(1)), ('beach', loader(2))])
+    res = net.mfeNew_validateByClass(7, modelpath=path)
+    assert list(res.keys()) == ['airplane', 'beach', 'Total']
+    for k in ('sradsgan_psnr', 'bicubic_ssim', 'sradsgan_ergas', 'bicubic_mse'):
+        assert abs(res['Total'][k] - (2 * res['airplane'][k] + 4 * res['beach'][k]) / 6) < 1e-9, k
+    lines = open(os.path.join(str(tmp_path), 'val_log.txt')).read().strip().splitlines()
+    assert len(lines) == 3 and all(ln.startswith('<epoch:  7, iter:       7, time:') for ln in lines)
+    # single image: 20x16 PNG, centre crop 12 -> x4 = 48
+    rgb = (torch.rand(16, 20, 3, generator=g) * 255).to(torch.uint8).numpy()
+    fn = os.path.join(str(tmp_path), 'tile.png')
+    Image.fromarray(rgb).save(fn)
+    sr, bc = net.mfe_test_single(fn, modelpath=path)
+    assert sr.shape == (48, 48, 3) and bc.shape == (48, 48, 3)
+    crop = Image.fromarray(rgb).crop((4, 2, 16, 14))
+    assert np.array_equal(bc, np.asarray(crop.resize((48, 48), Image.BICUBIC)))                 # bit-exact Pillow bicubic
+    x = torch.from_numpy(np.asarray(crop, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255).unsqueeze(0).to(DEV)
+    net.generator.eval()
+    with torch.no_grad():
+        want = (net.generator(x)[0] * 255.0).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(sr, want)
+    for tag, arr in (('SRADSGAN', sr), ('Bicubic', bc)):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(str(tmp_path), 'SR_%s_tile.png' % tag))), arr)
+
+
 def test_unsupported_reference_options_fail_loudly():
     from sradsgan_amd import trainer as T
     with pytest.raises(NotImplementedError):
