@@ -85,3 +85,119 @@ def training_batch(hr_u8, scale):
     lr_u8 = resize_u8(hr_u8, h // scale, w // scale, 'bicubic')
     bc_u8 = resize_u8(lr_u8, h, w, 'bicubic')
     return to_tensor(lr_u8), to_tensor(hr_u8), to_tensor(bc_u8)
+
+
+# --------------------------------------------------------------------------------------------- #
+# host side of the input pipeline: file listing + decode (data/dataset.py:88-101, 386-441) and the loader
+# (sradsgan.py:643-656: shuffle, drop_last).  Decode stays on the host (Pillow, worker threads); everything after the
+# uint8 HR tile -- LR / bicubic synthesis, to_tensor -- is `training_batch` / `test_batch` on the device.
+# --------------------------------------------------------------------------------------------- #
+
+IMG_EXTENSIONS = ('.png', '.jpg', '.jpeg', '.bmp', '.tif')                       # dataset.py:88-89 (case-sensitive there too)
+
+
+def is_image_file(filename):
+    return any(filename.endswith(ext) for ext in IMG_EXTENSIONS)
+
+
+def calculate_valid_crop_size(crop_size, scale_factor):                         # dataset.py:100-101
+    return crop_size - (crop_size % scale_factor)
+
+
+class TileFolder:
+    """The file side of RGB_TrainDatasetFromFolder / RGB_TestDatasetFromFolder (dataset.py:386-441): every image file of
+    `image_dirs`, each directory's names sorted, directories in the order given; item i = (uint8 [H, W, 3] RGB tensor,
+    file name).  The reference applies no crop or flip to training tiles (the augmentation flags are accepted and
+    ignored): tiles must already have the batch's common size."""
+
+    def __init__(self, image_dirs, is_gray=False, crop_size=216, scale_factor=3, **ignored_augmentation_flags):
+        import os
+        if is_gray:
+            raise NotImplementedError('TileFolder: RGB tiles only (is_gray=False is what the SRADSGAN trainer passes)')
+        self.image_filenames = []
+        for d in image_dirs:
+            self.image_filenames.extend(os.path.join(d, x) for x in sorted(os.listdir(d)) if is_image_file(x))
+        self.crop_size = calculate_valid_crop_size(crop_size, scale_factor)
+        self.scale_factor = scale_factor
+
+    def __len__(self):
+        return len(self.image_filenames)
+
+    def __getitem__(self, index):
+        import numpy as np
+        from PIL import Image
+        fn = self.image_filenames[index]
+        with Image.open(fn) as im:
+            arr = np.asarray(im.convert('RGB'), dtype=np.uint8)                   # dataset.py:92-97
+        return torch.from_numpy(arr.copy()), fn
+
+
+class DevicePrefetcher:
+    """DataLoader(shuffle, drop_last=True) (sradsgan.py:652, 656) for a dataset of uint8 tiles, delivering batches that
+    are already resident on the GPU: worker THREADS decode batch k+1 (Pillow releases the GIL) into one of two pinned
+    staging buffers while the device works on batch k, and the host-to-device copy runs on its own HIP stream; the
+    consumer's stream waits on the copy's event only.  Yields (uint8 [B, H, W, 3] device tensor, [file names])."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=False, drop_last=True, num_workers=4, seed=None):
+        if torch.device(device).type != 'cuda' or not torch.cuda.is_available():
+            raise RuntimeError('DevicePrefetcher stages through pinned memory to a GPU: needs a cuda device')
+        self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
+        self.shuffle, self.drop_last, self.num_workers = shuffle, drop_last, max(1, int(num_workers))
+        self.generator = torch.Generator()
+        if seed is not None:
+            self.generator.manual_seed(seed)
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
+        if self.drop_last and batches and len(batches[-1]) < self.batch_size:
+            batches.pop()
+        if not batches:
+            return
+        copy_stream = torch.cuda.Stream(device=self.device)
+        staging, staged_free = [None, None], [None, None]            # pinned buffers and "copy out of it finished" events
+
+        def decode(indices, slot):
+            items = list(pool.map(self.dataset.__getitem__, indices))
+            shape = (len(items),) + tuple(items[0][0].shape)
+            if staged_free[slot] is not None:
+                staged_free[slot].synchronize()                       # the previous copy out of this buffer is done
+            if staging[slot] is None or tuple(staging[slot].shape[1:]) != shape[1:] or staging[slot].shape[0] < shape[0]:
+                staging[slot] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            buf = staging[slot][:shape[0]]
+            for j, (t, _) in enumerate(items):
+                if tuple(t.shape) != shape[1:]:
+                    raise ValueError('DevicePrefetcher: tiles of one batch differ in size (%s vs %s): %s'
+                                     % (tuple(t.shape), shape[1:], items[j][1]))
+                buf[j].copy_(t)
+            return buf, [fn for _, fn in items]
+
+        with ThreadPoolExecutor(self.num_workers + 1) as outer, ThreadPoolExecutor(self.num_workers) as pool:
+            pending = outer.submit(decode, batches[0], 0)
+            for k in range(len(batches)):
+                buf, names = pending.result()
+                if k + 1 < len(batches):
+                    pending = outer.submit(decode, batches[k + 1], (k + 1) & 1)
+                with torch.cuda.stream(copy_stream):
+                    dev = buf.to(self.device, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(copy_stream)
+                staged_free[k & 1] = done
+                torch.cuda.current_stream(self.device).wait_event(done)
+                dev.record_stream(torch.cuda.current_stream(self.device))
+                yield dev, names
+
+
+def test_batch(hr_u8, scale):
+    """The test dataset's triplet (data/data.py:329-343): LR by torchvision Resize's default BILINEAR, the bicubic
+    image from that LR.  hr_u8: [N, H, W, 3] uint8 on the device.  Returns (lr, hr, bc) float32 NCHW."""
+    n, h, w, c = hr_u8.shape
+    lr_u8 = resize_u8(hr_u8, h // scale, w // scale, 'bilinear')
+    bc_u8 = resize_u8(lr_u8, h, w, 'bicubic')
+    return to_tensor(lr_u8), to_tensor(hr_u8), to_tensor(bc_u8)

@@ -101,10 +101,15 @@ class SRADSGAN(object):
                               weight_content=self.weight_content, weight_gan=self.weight_gan, lambda_gp=self.lambda_gp,
                               clip_value=self.clip_value, use_gp=bool(self.gp), grad_sync=getattr(self, 'grad_sync', None))
 
-    def _batch(self, item):
-        """(lr, hr, bc) device float tensors from a loader item: the reference's 4-tuple or a uint8 HR batch."""
+    def _batch(self, item, test=False):
+        """(lr, hr, bc) device float tensors from a loader item: the reference's 4-tuple, a uint8 HR batch [B,H,W,3],
+        or data.DevicePrefetcher's (uint8 batch, file names).  uint8 tiles get the reference's per-sample transforms
+        on the device: bicubic LR for training (dataset.py:418-436), bilinear LR for the test set (data.py:329-343)."""
+        if isinstance(item, (tuple, list)) and len(item) == 2 and torch.is_tensor(item[0]) and item[0].dtype == torch.uint8:
+            item = item[0]
         if torch.is_tensor(item) and item.dtype == torch.uint8:
-            return sdata.training_batch(item.to(self.device), self.scale_factor)
+            make = sdata.test_batch if test else sdata.training_batch
+            return make(item.to(self.device), self.scale_factor)
         lr, hr, bc = item[0], item[1], item[2]
         return lr.to(self.device).float(), hr.to(self.device).float(), bc.to(self.device).float()
 
@@ -168,7 +173,7 @@ class SRADSGAN(object):
         generator.eval()                                                                         # :1288
         start = time.time()
         for item in loader:
-            imgs_lr, imgs_hr, imgs_bc = self._batch(item)
+            imgs_lr, imgs_hr, imgs_bc = self._batch(item, test=True)
             out = sval.evaluate(generator, imgs_lr, imgs_hr, self.scale_factor, bicubic=imgs_bc)
             img_num += imgs_hr.size(0)
             for k in ('mse', 'psnr', 'ssim', 'ergas'):
