@@ -136,25 +136,36 @@ class DevicePrefetcher:
     """DataLoader(shuffle, drop_last=True) (sradsgan.py:652, 656) for a dataset of uint8 tiles, delivering batches that
     are already resident on the GPU: worker THREADS decode batch k+1 (Pillow releases the GIL) into one of two pinned
     staging buffers while the device works on batch k, and the host-to-device copy runs on its own HIP stream; the
-    consumer's stream waits on the copy's event only.  Yields (uint8 [B, H, W, 3] device tensor, [file names])."""
+    consumer's stream waits on the copy's event only.  Yields (uint8 [B, H, W, 3] device tensor, [file names]).
+    rank / world: this process's shard under data parallelism -- every rank draws the same permutation (same seed) and
+    keeps every world-th index, all ranks the same number of batches."""
 
-    def __init__(self, dataset, batch_size, device, shuffle=False, drop_last=True, num_workers=4, seed=None):
+    def __init__(self, dataset, batch_size, device, shuffle=False, drop_last=True, num_workers=4, seed=None, rank=0, world=1):
         if torch.device(device).type != 'cuda' or not torch.cuda.is_available():
             raise RuntimeError('DevicePrefetcher stages through pinned memory to a GPU: needs a cuda device')
         self.dataset, self.batch_size, self.device = dataset, int(batch_size), torch.device(device)
         self.shuffle, self.drop_last, self.num_workers = shuffle, drop_last, max(1, int(num_workers))
+        self.rank, self.world = int(rank), int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError('DevicePrefetcher: rank %d outside world %d' % (self.rank, self.world))
         self.generator = torch.Generator()
+        if seed is None and self.world > 1:
+            seed = 0                                  # ranks must draw the same permutation to get disjoint shards
         if seed is not None:
             self.generator.manual_seed(seed)
 
     def __len__(self):
-        n = len(self.dataset)
+        n = len(self.dataset) // self.world
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        if self.world > 1:                            # data parallel: disjoint shards of the same permutation (SURVEY 8e)
+            from .dp import shard_indices
+            order = shard_indices(order, self.rank, self.world)
+            n = len(order)
         batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
         if self.drop_last and batches and len(batches[-1]) < self.batch_size:
             batches.pop()

@@ -109,3 +109,34 @@ def broadcast_module(module, src=0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src=src, group=group)
+
+
+def rank_world(group=None):
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def broadcast_floats(values, src=0, device=None, group=None):
+    """The python floats `values` as rank `src` holds them, on every rank (validation metrics / rollback decisions are
+    taken from rank 0).  NaN survives.  No-op with one rank."""
+    rank, world = rank_world(group)
+    vals = [float(v) for v in values]
+    if world == 1:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return [float(v) for v in t.cpu()]
+
+
+def shard_indices(order, rank, world):
+    """Rank `rank`'s share of the (already shuffled, identical on all ranks) index list: every world-th index,
+    truncated so that all ranks get the same count (the tail is dropped like DataLoader's drop_last)."""
+    per = len(order) // world
+    return order[rank:per * world:world]
+
+
+def barrier(group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group)

@@ -22,6 +22,7 @@ import torch
 
 from . import checkpoint as ckpt
 from . import data as sdata
+from . import dp
 from . import validate as sval
 from .model import Discriminator, FeatureExtractor, GeneratorResNet, ResGroup
 from .train_step import TrainStep
@@ -71,6 +72,10 @@ class SRADSGAN(object):
         self.n_residual_blocks = getattr(args, 'n_residual_blocks', 12)
         self.n_basic_blocks = getattr(args, 'n_basic_blocks', 3)
         self.train_loader, self.test_loader = train_loader, test_loader
+        # data parallel: one process per GPU under torch.distributed; replicas start identical (broadcast
+        # from rank 0), gradients are averaged by TrainStep's GradSync, BatchNorm stays local, rank 0 owns files and
+        # logs, validation results and with them every rollback decision are rank 0's
+        self.rank, self.world = dp.rank_world()
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.generator = self.discriminator = self.feature_extractor = None
         self.step = None
@@ -97,6 +102,12 @@ class SRADSGAN(object):
             self.discriminator.apply(weights_init_normal)
         self.generator.to(self.device), self.discriminator.to(self.device), self.feature_extractor.to(self.device)
         self.feature_extractor.eval()                                                           # :727
+        if self.world > 1:
+            dp.broadcast_module(self.generator, 0), dp.broadcast_module(self.discriminator, 0)
+            dp.broadcast_module(self.feature_extractor, 0)
+            if getattr(self, 'grad_sync', None) is None:
+                self.grad_sync = dp.GradSync(self.world)
+            self._alpha_rng = np.random.RandomState(1234 + self.rank)                           # alpha drawn per rank
         self.step = TrainStep(self.generator, self.discriminator, self.feature_extractor, lr=self.lr, b1=self.b1, b2=self.b2,
                               weight_content=self.weight_content, weight_gan=self.weight_gan, lambda_gp=self.lambda_gp,
                               clip_value=self.clip_value, use_gp=bool(self.gp), grad_sync=getattr(self, 'grad_sync', None))
@@ -133,7 +144,8 @@ class SRADSGAN(object):
             n_batches = 0
             for i, item in enumerate(self.train_loader):
                 imgs_lr, imgs_hr, _ = self._batch(item)
-                alpha = torch.from_numpy(np.random.random((imgs_hr.size(0), 1, 1, 1))).float().to(self.device)   # :609
+                rng = getattr(self, '_alpha_rng', None) or np.random
+                alpha = torch.from_numpy(rng.random_sample((imgs_hr.size(0), 1, 1, 1))).float().to(self.device)   # :609
                 out = self.step(imgs_lr, imgs_hr, alpha)                                        # :829-892
                 step_count += 1
                 n_batches += 1
@@ -142,23 +154,29 @@ class SRADSGAN(object):
                     self.log_dict['loss_G'], self.log_dict['loss_D'] = lg, ld
                     rlt = OrderedDict(model=self.model_name, epoch=epoch, iters=step_count, time=time.time() - start_time)
                     rlt.update(self.log_dict)
-                    print(sval.append_log(self.loss_log_path, 'train', rlt))                   # :898-906, 963-969
+                    if self.rank == 0:
+                        print(sval.append_log(self.loss_log_path, 'train', rlt))               # :898-906, 963-969
                 epoch_loss_G = epoch_loss_G + out['loss_G']
                 epoch_loss_D = epoch_loss_D + out['loss_D']
             avg_loss_G.append(float(epoch_loss_G) / max(n_batches, 1))                          # :975-976
             avg_loss_D.append(float(epoch_loss_D) / max(n_batches, 1))
             val = self.validate(epoch=epoch, mode='train', save_img=((epoch + 1) % self.save_epochs == 0))   # :978
+            val = tuple(dp.broadcast_floats(val, 0, self.device))                               # rank 0's numbers decide
             history.append(dict(epoch=epoch, loss_G=avg_loss_G[-1], loss_D=avg_loss_D[-1], psnr=val[0], ssim=val[1],
                                 ergas=val[2], lpips=val[3]))
-            self.save_epoch_network(save_dir=model_dir, network=self.generator, network_label='generator', iter_label=epoch + 1)
-            self.save_epoch_network(save_dir=model_dir, network=self.discriminator, network_label='discriminator', iter_label=epoch + 1)
+            if self.rank == 0:
+                self.save_epoch_network(save_dir=model_dir, network=self.generator, network_label='generator', iter_label=epoch + 1)
+                self.save_epoch_network(save_dir=model_dir, network=self.discriminator, network_label='discriminator', iter_label=epoch + 1)
+            dp.barrier()                                                                        # files exist before any rank rolls back
             reload_g = lambda n: self.load_epoch_network(model_dir + '/generator_param_epoch_%d.pkl' % n, self.generator)
             epoch, rolled = control.update(epoch, val[0], val[1], val[2], val[3] if not math.isnan(val[3]) else 10000,
                                            step=self.step, on_rollback=reload_g)               # :985-1036
             self.lr = control.lr
             if rolled:
                 print('optimizer_G_Learning rate decay: lr={}'.format(self.step.lr_G))
-        self.save_model(epoch=None)
+        if self.rank == 0:
+            self.save_model(epoch=None)
+        dp.barrier()
         return history
 
     # ------------------------------------------------------------------ validation -------------- #
@@ -193,6 +211,8 @@ class SRADSGAN(object):
             for k in ('mse', 'psnr', 'ssim', 'ergas'):
                 rlt['%s_%s' % (prefix, k)] = avg['%s_%s' % (prefix, k)]
             rlt['%s_lpips' % prefix] = float('nan')
+        if self.rank != 0:
+            return
         os.makedirs(self.save_dir, exist_ok=True)
         print(sval.append_log(self.val_log_path, 'val', rlt))
 

@@ -46,3 +46,45 @@ def test_gradsync_mean_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert [open(os.path.join(str(tmp_path), 'ok%d' % r)).read() for r in range(2)] == ['1', '1']
+
+
+def _control_worker(rank, world, port, out_dir):
+    """The trainer's data-parallel control plane (sradsgan_amd/trainer.py under torch.distributed): rank 0's validation
+    numbers reach every rank (NaN included), so every rank replays the same PlateauRollback sequence; shards of one
+    permutation are disjoint, equal-sized and cover the prefix DataLoader(drop_last) would keep."""
+    import math
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sradsgan_amd import dp
+    from sradsgan_amd.checkpoint import PlateauRollback
+    ok = dp.rank_world() == (rank, world)
+    control = PlateauRollback(2e-4)
+    epoch, trace = 0, []
+    r0 = [20.0, 21.0, 20.5, 20.4, 20.3, 20.2, 20.1, 20.0, 19.9, 22.0]      # psnr, psnr, ssim, ergas improve, then 5 misses
+    psnr_by_rank = [r0, [25.0, 19.0, 26.0, 18.0, 27.0, 17.0, 28.0, 16.0, 29.0, 15.0]][rank]
+    for i in range(10):
+        local = (psnr_by_rank[i], 0.5, 9.0, float('nan'))                 # ranks disagree on purpose; lpips slot is NaN
+        val = dp.broadcast_floats(local, 0)
+        ok = ok and val[0] == r0[i] and math.isnan(val[3])
+        epoch, rolled = control.update(epoch, val[0], val[1], val[2], 10000 if math.isnan(val[3]) else val[3])
+        trace.append((epoch, rolled, control.lr))
+        dp.barrier()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, trace)
+    ok = ok and gathered[0] == gathered[1] and sum(r for _, r, _ in trace) == 1                 # same decisions, one rollback
+    g = torch.Generator().manual_seed(0)
+    order = torch.randperm(11, generator=g).tolist()
+    mine = dp.shard_indices(order, rank, world)
+    shards = [None] * world
+    dist.all_gather_object(shards, mine)
+    ok = ok and len(shards[0]) == len(shards[1]) == 5 and not set(shards[0]) & set(shards[1])
+    ok = ok and sorted(shards[0] + shards[1]) == sorted(order[:10])
+    open(os.path.join(out_dir, 'ctl%d' % rank), 'w').write('1' if ok else '0')
+    dist.destroy_process_group()
+
+
+def test_trainer_control_plane_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_control_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), 'ctl%d' % r)).read() for r in range(2)] == ['1', '1']
