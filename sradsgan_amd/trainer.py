@@ -71,6 +71,8 @@ class SRADSGAN(object):
         # generator depth: the reference hard-codes 12 groups x 3 blocks (:669-671); overridable for tests
         self.n_residual_blocks = getattr(args, 'n_residual_blocks', 12)
         self.n_basic_blocks = getattr(args, 'n_basic_blocks', 3)
+        self.pretrained_generator = getattr(args, 'pretrained_generator', None)      # chain training, see _build
+        self.pretrained_discriminator = getattr(args, 'pretrained_discriminator', None)
         self.train_loader, self.test_loader = train_loader, test_loader
         # data parallel: one process per GPU under torch.distributed; replicas start identical (broadcast
         # from rank 0), gradients are averaged by TrainStep's GradSync, BatchNorm stays local, rank 0 owns files and
@@ -100,6 +102,17 @@ class SRADSGAN(object):
         else:
             self.generator.apply(weights_init_normal)                                           # :713-714
             self.discriminator.apply(weights_init_normal)
+            # chain training (:716-721, commented out in the reference and edited by hand per scale): start from the
+            # previous scale's checkpoints.  strict=False there still raises on shape mismatches, so the partial load
+            # is shape-aware (checkpoint.load_compatible): the up-sampler conv keeps its fresh init across 2^n <-> 3^n
+            self.chain_report = {}
+            for label, net in (('generator', self.generator), ('discriminator', self.discriminator)):
+                path = getattr(self, 'pretrained_' + label, None)
+                if path:
+                    self.chain_report[label] = ckpt.load_compatible(net, torch.load(path, map_location='cpu'))
+                    print('%s initialised from %s: %d tensors loaded, %d kept their init' % (
+                        label, path, len(self.chain_report[label][0]),
+                        len(self.chain_report[label][1]) + len(self.chain_report[label][2])))
         self.generator.to(self.device), self.discriminator.to(self.device), self.feature_extractor.to(self.device)
         self.feature_extractor.eval()                                                           # :727
         if self.world > 1:
@@ -314,3 +327,25 @@ class SRADSGAN(object):
         ckpt.load_epoch_network(path, self.generator)
         print('Trained model is loaded.')
         return True
+
+
+def chain_train(args, scales, loaders, trainer_cls=SRADSGAN):
+    """BASELINE configs[4]: the multi-scale chain x2 -> x3 -> x4 -> x8 -> x9 the reference runs by hand (re-launching
+    main_sradsgan.py per --scale_factor after editing the paths at sradsgan.py:716-721).  One trainer per scale, results
+    under <save_dir>/x<scale>; every stage after the first starts from the previous stage's final generator /
+    discriminator files through the shape-aware partial load.  `loaders(scale)` -> (train_loader, test_loader) for
+    that scale's tile size.  Returns {scale: (history, chain_report)}."""
+    out, prev = OrderedDict(), None
+    for scale in scales:
+        a = argparse.Namespace(**vars(args))
+        a.scale_factor, a.epoch = scale, 0
+        a.save_dir = os.path.join(args.save_dir, 'x%d' % scale)
+        if prev is not None:
+            a.pretrained_generator = os.path.join(prev, 'model', 'generator_param.pkl')
+            a.pretrained_discriminator = os.path.join(prev, 'model', 'discriminator_param.pkl')
+        train_loader, test_loader = loaders(scale)
+        net = trainer_cls(a, train_loader=train_loader, test_loader=test_loader)
+        history = net.train()
+        out[scale] = (history, getattr(net, 'chain_report', {}))
+        prev = a.save_dir
+    return out

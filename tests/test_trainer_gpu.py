@@ -91,6 +91,31 @@ def test_validate_by_class_and_single_image(tmp_path):
         assert np.array_equal(np.asarray(Image.open(os.path.join(str(tmp_path), 'SR_%s_tile.png' % tag))), arr)
 
 
+def test_chain_training_two_scales(tmp_path):
+    """x2 -> x3 with one tiny epoch each: stage 2 starts from stage 1's files; across 2^n -> 3^n only the up-sampler conv
+    (64 -> 256 vs 64 -> 576) keeps its fresh init, the discriminator loads completely."""
+    from sradsgan_amd import trainer as T
+    g = torch.Generator().manual_seed(9)
+
+    def loaders(scale):
+        side = 12 * scale
+        train = [torch.randint(0, 256, (2, side, side, 3), generator=g, dtype=torch.uint8) for _ in range(2)]
+        test = [torch.randint(0, 256, (2, side, side, 3), generator=g, dtype=torch.uint8)]
+        return train, test
+    args = T.default_args(num_epochs=1, batch_size=2, save_dir=str(tmp_path), sample_interval=1, n_residual_blocks=1,
+                          n_basic_blocks=1)
+    res = T.chain_train(args, [2, 3], loaders)
+    assert list(res.keys()) == [2, 3] and res[2][1] == {}
+    loaded, missing, mismatch, unused = res[3][1]['generator']
+    assert sorted(mismatch) == ['GAB_UP.upsampling.0.bias', 'GAB_UP.upsampling.0.weight'] and not missing and not unused
+    assert len(loaded) == 38
+    d_loaded, d_missing, d_mismatch, d_unused = res[3][1]['discriminator']
+    assert not d_missing and not d_mismatch and not d_unused
+    for scale in (2, 3):
+        assert os.path.exists(os.path.join(str(tmp_path), 'x%d' % scale, 'model', 'generator_param.pkl'))
+        assert all(torch.isfinite(torch.tensor([h['loss_G'], h['psnr']])).all() for h in res[scale][0])
+
+
 def test_unsupported_reference_options_fail_loudly():
     from sradsgan_amd import trainer as T
     with pytest.raises(NotImplementedError):
