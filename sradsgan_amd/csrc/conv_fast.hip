@@ -657,6 +657,7 @@ struct PatchGeom {
   int PH, PW, tiles_h, tiles_w;    // output patch and patches per image
   int PWP, PR, npieces;            // patch width incl. halo, patch rows, 16-row DMA pieces
   int lo_h, lo_w;                  // source pixel of patch row (0,0) = (oh0 + lo_h, ow0 + lo_w)
+  unsigned gmap;                   // 8 x 4 bits: pixel group held by lane-row group i (patch_pixel)
 };
 
 template <int N>
@@ -668,6 +669,35 @@ template <int I>
 struct IC {
   static constexpr int value = I;
 };
+
+// Lane-row r (0..127) of a patch tile -> output pixel (orow, ocol) of the PH x PW tile; orow == PH marks a dead row.
+// Patch rows are 64 bytes with the 16-byte quad XOR-swizzled by (row >> 2) & 3, and a ds_read_b128 is served in four
+// lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): a group is conflict-free exactly when its 16 patch rows are
+// distinct mod 16, which 32 CONSECUTIVE patch rows give.  With the plain row-major order (r / PW, r % PW) every run of
+// lanes that crosses the end of a tile row jumps by the halo (+2 rows) and lanes collide -- for the 54 x 54 images that
+// was every group: 44 % of the LDS-active cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+// Here the 128 lane-rows are 8 groups of 16: "pixel group" q < PH * (PW / 16) is a 16-pixel run of ONE image row, the
+// PW % 16 left-over columns of all rows are packed into the remaining group(s); gmap says which pixel group each
+// lane-row group holds, and plan_patch orders them so that the two runs sharing lanes 0-31 / 32-63 of an MFMA row block
+// start at patch rows that are congruent mod 16 (rows i and i + 4 for the 20-row pitch of PW = 18).
+// PH * PW <= 128 implies at most 8 groups.
+__device__ __forceinline__ void patch_pixel(int r, int PH, int PW, unsigned gmap, int& orow, int& ocol) {
+  const int a = PW >> 4, b = PW & 15;
+  const int grp = (gmap >> (4 * (r >> 4))) & 15, j = r & 15;
+  const int nfull = PH * a;
+  if (grp < nfull) {
+    orow = grp / a;
+    ocol = (grp - orow * a) * 16 + j;
+  } else if (b > 0) {
+    const int idx = (grp - nfull) * 16 + j;
+    orow = idx / b;
+    ocol = 16 * a + (idx - orow * b);
+    if (orow >= PH) { orow = PH; ocol = 0; }
+  } else {
+    orow = PH;
+    ocol = 0;
+  }
+}
 
 template <int BN, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wt,
@@ -765,8 +795,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int r = wm * WTM + t * 32 + l31;
-    const int orow = r / pg.PW, ocol = r - orow * pg.PW;
-    const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;   // dead rows (r >= PH*PW) read pixel 0, never stored
+    int orow, ocol;
+    patch_pixel(r, pg.PH, pg.PW, pg.gmap, orow, ocol);
+    const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;   // dead rows read pixel 0, never stored
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int a_th = (g.dh0 + (tap / 3) * g.dhs) - pg.lo_h, a_tw = (g.dw0 + (tap % 3) * g.dws) - pg.lo_w;
@@ -868,7 +899,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int row = idx / QPRW, cq = idx - row * QPRW;
       const float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
       const int r = wm * WTM + t * 32 + row;
-      const int orow = r / pg.PW, ocol = r - orow * pg.PW;
+      int orow, ocol;
+      patch_pixel(r, pg.PH, pg.PW, pg.gmap, orow, ocol);
       const int oh = oh0 + orow, ow = ow0 + ocol;
       const int n = n0 + wn * WTN + cq * 4;
       if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
@@ -1727,7 +1759,9 @@ static bool plan_patch(const FastGeom& g, PatchGeom* pg) {
     if (ph > g.OH) ph = g.OH;
     if (ph < 1 || (ph + 2) * (pw + 2) > 192) continue;
     const long tiles = (long)cdiv(g.OH, ph) * cdiv(g.OW, pw);
-    const double eff = (double)g.OH * g.OW / ((double)tiles * 128.0);
+    // among equally efficient shapes prefer the one whose rows are mostly whole 16-pixel runs: those lane groups read
+    // the patch without LDS bank conflicts (patch_pixel)
+    const double eff = (double)g.OH * g.OW / ((double)tiles * 128.0) + 1e-6 * (double)(pw - pw % 16) / pw;
     if (eff > best + 1e-9) {
       best = eff;
       pg->PH = ph; pg->PW = pw;
@@ -1741,6 +1775,34 @@ static bool plan_patch(const FastGeom& g, PatchGeom* pg) {
   pg->npieces = cdiv(pg->PR, 16);
   pg->lo_h = g.dhs > 0 ? g.dh0 : g.dh0 + 2 * g.dhs;
   pg->lo_w = g.dws > 0 ? g.dw0 : g.dw0 + 2 * g.dws;
+  // lane-row group order (patch_pixel): pairs of full 16-pixel runs whose first patch rows are congruent mod 16 first,
+  // then the runs without a partner, then the left-over / dead groups
+  const int a = pg->PW >> 4;
+  const int nfull = pg->PH * a < 8 ? pg->PH * a : 8;
+  auto base = [&](int q) { return ((q / a) * pg->PWP + (q % a) * 16) & 15; };
+  int fin[8], nf = 0, singles[8], ns = 0;
+  bool used[8] = {false, false, false, false, false, false, false, false};
+  for (int q = 0; q < nfull; ++q) {
+    if (used[q]) continue;
+    used[q] = true;
+    int partner = -1;
+    for (int p2 = q + 1; p2 < nfull; ++p2)
+      if (!used[p2] && base(p2) == base(q)) {
+        partner = p2;
+        break;
+      }
+    if (partner >= 0) {
+      used[partner] = true;
+      fin[nf++] = q;
+      fin[nf++] = partner;
+    } else {
+      singles[ns++] = q;
+    }
+  }
+  for (int i = 0; i < ns; ++i) fin[nf++] = singles[i];
+  for (int q = nfull; q < 8; ++q) fin[nf++] = q;
+  pg->gmap = 0;
+  for (int i = 0; i < 8; ++i) pg->gmap |= (unsigned)(fin[i] & 15) << (4 * i);
   return true;
 }
 
