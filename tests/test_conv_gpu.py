@@ -257,7 +257,8 @@ def test_conv_math_modes_against_fp64(mode, tol):
     assert _rel(db, dyd.sum((0, 2, 3))) < 5e-6
 
 
-@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (3, 256, 9, 20, 256), (2, 64, 27, 27, 512)])
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (3, 256, 9, 20, 256), (2, 64, 27, 27, 512),
+                                  (1, 64, 3, 64, 64), (2, 64, 3, 70, 128), (1, 64, 108, 108, 64)])   # the last three: tile rows of 32+ pixels (two 16-pixel runs per row, with and without left-over columns), 7x18 tiles on a 108-wide image
 def test_patch_conv_kernel_bit_identical_to_dma_kernel(case):
     """conv_patch_kernel (resident halo patch, in-place hi/lo conversion) must reproduce fast_conv_dma_kernel<bf16x3>
     bit for bit -- same split, same product and chunk order -- on ragged images (edge patches, dead GEMM rows), for
