@@ -715,6 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   constexpr int EPI_B = NW * 32 * WTN * 4;
   constexpr int LDS_B = 2 * PATCH_B + 3 * BSTAGE_B > EPI_B ? 2 * PATCH_B + 3 * BSTAGE_B : EPI_B;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+  __shared__ int pix_tab[128];                      // lane-row -> (orow << 16 | ocol): patch_pixel (two integer divisions) once per row
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -727,6 +728,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   const int ty = prem / pg.tiles_w, tx = prem - ty * pg.tiles_w;
   const int oh0 = ty * pg.PH, ow0 = tx * pg.PW;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  if (tid < 128) {
+    int pr_, pc_;
+    patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
+    pix_tab[tid] = (pr_ << 16) | pc_;
+  }
+  __syncthreads();
 
   // ---- A patch DMA: piece p = k*NW + wave covers patch rows 16p .. 16p+15; this lane feeds (row, slot lane&3).
   // Every wave always moves MAXP pieces (rows past the patch come from the zero block and are never read), so the
@@ -795,8 +802,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int r = wm * WTM + t * 32 + l31;
-    int orow, ocol;
-    patch_pixel(r, pg.PH, pg.PW, pg.gmap, orow, ocol);
+    const int pt = pix_tab[r];
+    const int orow = pt >> 16, ocol = pt & 0xffff;
     const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;   // dead rows read pixel 0, never stored
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -899,8 +906,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int row = idx / QPRW, cq = idx - row * QPRW;
       const float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
       const int r = wm * WTM + t * 32 + row;
-      int orow, ocol;
-      patch_pixel(r, pg.PH, pg.PW, pg.gmap, orow, ocol);
+      const int pt = pix_tab[r];
+      const int orow = pt >> 16, ocol = pt & 0xffff;
       const int oh = oh0 + orow, ow = ow0 + ocol;
       const int n = n0 + wn * WTN + cq * 4;
       if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
