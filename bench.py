@@ -9,6 +9,9 @@ A "step" is one full training iteration of the reference's batch loop (SRADSGAN/
 double backward, Adam(D), weight clip -- on a per-GPU batch of 32 synthetic 54x54 -> 216x216 tiles
 (BASELINE.json configs[2]; with N>1 ranks, configs[3]: weak scaling, global batch 32*N, RCCL
 all-reduce of G and D gradients).  Inputs are resident in HBM before the timed region.
+Before the W warm-up steps every rank runs --spinup-steps (default 25, reported as `spinup_steps`) further untimed
+steps: a fresh box runs the first ~1 s of GPU work 20-30 % slower, which 3 warm-up steps do not cover; the timed region
+is still exactly K steps between two barrier + synchronize pairs.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, fp32 MFMA) timed with HIP
@@ -57,6 +60,10 @@ def parse():
                          "(default: the library default, sradsgan_amd/_hip.py DEFAULT_CONV_MATH)")
     ap.add_argument('--no-fp32-line', action='store_true', help='skip the short extra run in exact-fp32 conv arithmetic')
     ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--spinup-steps', type=int, default=25,
+                    help='untimed device spin-up steps before the W warm-up steps (same count on every rank): a fresh '
+                         'box runs the first ~1 s of GPU work 20-30 %% slower (clocks / first touch), which a few '
+                         'warm-up steps do not cover; reported in the JSON line')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--workload', choices=['train', 'infer', 'srgan', 'sragan', 'edsr'], default='train',
                     help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]; not the headline line)")
@@ -214,7 +221,7 @@ def run_inference(args, device):
     else:
         run = validate.GraphedEvaluator(G, SCALE)           # launch-bound at this batch size: replay a captured hipGraph
         run = (lambda ev: (lambda: ev(lr, hr)))(run)
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.spinup_steps) + args.warmup):    # untimed spin-up + warm-up
         out = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -296,7 +303,7 @@ def run_sibling(args, device):
             opt.step()
             return loss.detach()
         name = 'EDSR x2 L1 training step (Net(3,256,32,2), BASELINE configs[0]), LR 108x108 -> HR 216x216, batch %d' % B
-    for _ in range(args.warmup):
+    for _ in range(max(0, args.spinup_steps) + args.warmup):    # untimed spin-up + warm-up
         out = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -388,6 +395,9 @@ def main():
         torch.cuda.synchronize()
 
     trace = []
+    for _ in range(max(0, args.spinup_steps)):                  # untimed, before the contract's W warm-up steps
+        step(lr, hr, alpha)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step(lr, hr, alpha)
         if args.trace_losses:
@@ -443,6 +453,7 @@ def main():
             'metric': 'training images/sec (216x216, x4)', 'value': round(value, 3), 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'spinup_steps': max(0, args.spinup_steps),
             'config': {'workload': 'SRADSGAN full GAN x4 training step (G+D+VGG perceptual, WGAN-GP), '
                                    'LR 54x54 -> HR 216x216, per-GPU batch %d' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,

@@ -10,7 +10,7 @@ timeout 600 python bench.py --no-cpu-baseline --conv-math fp32 2>&1 | tail -1 > 
 timeout 600 python bench.py --workload infer 2>&1 | tail -1 > $E/bench_infer.json; cut -c1-260 $E/bench_infer.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $E/bench_n1_rccl_single_rank.json; cut -c1-200 $E/bench_n1_rccl_single_rank.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --steps 4 --warmup 2 > $E/step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
 cd $R
 f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 60 > $E/step_kernel_stats.txt; head -12 $E/step_kernel_stats.txt
 bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -9 $E/roofline2.log
