@@ -33,6 +33,8 @@ if ROOT not in sys.path:
 # RCCL adds its own -- keep enough queues that the two compute streams never share one (measured: sharing
 # costs 10 % of the step).  Must be set before the HIP runtime initialises.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 PER_GPU_BATCH = 32
 SCALE, LR_SIDE = 4, 54
