@@ -322,3 +322,29 @@ def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
     got = {k: float(v) for k, v in step2(*batches[1]).items() if k != 'gen_hr'}
     for k in want:
         assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
+
+
+def test_training_step_is_deterministic():
+    """Two runs of the same two iterations from the same weights give bit-identical scalars and weights: split-K
+    reductions are ordered, weight gradients of one parameter are accumulated on one stream in program order, and no
+    kernel uses floating-point atomics -- the three-stream overlap does not change a single bit."""
+    from sradsgan_amd.train_step import TrainStep
+    results = []
+    for run in range(2):
+        (hg, hd, hf), _ = build_pair(2, 2, 4, DEV)
+        step = TrainStep(hg, hd, hf)
+        scal = []
+        for it in range(2):
+            lr_img = O.det_fill('det.lr.%d' % it, (4, 3, 24, 24), 0.5, 0.5).to(DEV)
+            hr_img = O.det_fill('det.hr.%d' % it, (4, 3, 96, 96), 0.5, 0.5).to(DEV)
+            alpha = O.det_fill('det.alpha.%d' % it, (4, 1, 1, 1), 0.5, 0.5).to(DEV)
+            out = step(lr_img, hr_img, alpha)
+            scal.append(torch.stack([out[k].double() for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')]).cpu())
+        torch.cuda.synchronize()
+        results.append((scal, [p.detach().cpu().clone() for p in list(hg.parameters()) + list(hd.parameters())],
+                        [b.detach().cpu().clone() for b in hd.buffers()]))
+    for a, b in zip(results[0][0], results[1][0]):
+        assert torch.equal(a, b), (a, b)
+    for group in (1, 2):
+        for a, b in zip(results[0][group], results[1][group]):
+            assert torch.equal(a, b)
