@@ -45,7 +45,8 @@ int srhip_abi_version(void);
  *          20 register-staged kernels only, 21 no patch kernel, 1..8 fixed tile shapes of the register-staged kernel
  *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, >= 10 register-staged
  *          kernel, >= 100 split-K block target of the row-tap kernel
- *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (timing only, wrong results) */
+ *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (0x100 / 0x200: timing only, wrong results;
+ *          0x400: plain instead of non-temporal epilogue stores, correct results) */
 int srhip_debug_set(int key, int value);
 
 /* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *
