@@ -16,7 +16,7 @@ is still exactly K steps between two barrier + synchronize pairs.
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, fp32 MFMA) timed with HIP
                   events on the launch stream: algorithmic FLOPs per launch / average duration;
-  exact_fp32_mode -- the same job re-timed (4 steps) with the conv contraction in exact fp32 (DESIGN.md section 3);
+  exact_fp32_mode -- the same job re-timed over the same K steps with the conv contraction in exact fp32 (DESIGN.md section 3);
   cpu_baseline -- the CPU oracle (oracle/sradsgan_ref.py, a port of the reference step) timed on the
                   host cores of this box on a bounded sample (rank 0, N=1 only).
 """
@@ -44,6 +44,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, d
 # multiply-accumulate, so the ceiling for ALGORITHMIC flops is a third of the bf16 peak
 MATH_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'f32 MFMA dense'),
              'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 'bf16 MFMA dense 2500 TFLOP/s / 3 products per fp32 MAC')}
+# headline `dtype`: tensors, accumulators and reductions are fp32 in both modes; the label says how the conv products are formed
+DTYPE_LABEL = {'fp32': 'f32 (exact fp32 products)', 'bf16x3': 'f32 (split-bf16 products: 3 bf16 MFMA terms per fp32 multiply, fp32 accumulate)'}
 GF_PER_IMG_ITER = 362.6                # algorithmic GFLOP per image per training iteration (x4)
 
 
@@ -362,20 +364,55 @@ def cpu_baseline_subprocess(iters, timeout_s=240):
                 'sample': 'CPU leg exceeded its %d s bound on this host' % timeout_s}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU, the same
+    environment torch.distributed.run would give them -- BEFORE this process touches the GPU (it never does: children
+    are new processes, nothing is exec'd over an initialised runtime).  Rank 0's stdout (the JSON line) is passed through."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                     # counting devices does not initialise the HIP runtime
+    if have < args.gpus:
+        print('bench.py: --gpus %d but only %d GPU(s) are visible on this node' % (args.gpus, have), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                  # the exact children we started, never a pattern
+    return rc
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.cpu_iters)), flush=True)
         return
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and rank == 0:
-        print('bench.py: WORLD_SIZE=%d but --gpus %d; launch with torch.distributed.run --nproc-per-node %d'
-              % (world, args.gpus, args.gpus), file=sys.stderr)
+    if world != args.gpus:
+        # a line with n_gpus != --gpus would void the scaling record: refuse instead of running a different job
+        raise SystemExit('bench.py: WORLD_SIZE=%d but --gpus %d; run `python bench.py --gpus %d` (it starts the ranks itself) '
+                         'or torch.distributed.run --nproc-per-node %d' % (world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
     from sradsgan_amd import _hip
@@ -457,11 +494,11 @@ def main():
     alt = None
     if conv_math == 'bf16x3' and not args.no_fp32_line:
         ops.set_conv_math('fp32')
-        for _ in range(2):
+        for _ in range(max(2, args.warmup)):
             step(lr, hr, alpha)
         barrier()
         t1 = time.perf_counter()
-        for _ in range(4):
+        for _ in range(args.steps):                         # the same K steps as the headline
             step(lr, hr, alpha)
         barrier()
         dt1 = time.perf_counter() - t1
@@ -470,8 +507,9 @@ def main():
             t = torch.tensor([dt1], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt1 = float(t.item())
-        alt = {'conv_math': 'fp32', 'value': round(world * B * 4 / dt1, 3), 'ms_per_step': round(dt1 / 4 * 1e3, 3), 'steps': 4,
-               'step_frac_of_mfma_peak': round(world * B * 4 / dt1 * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)}
+        alt = {'conv_math': 'fp32', 'dtype': 'f32 (exact fp32 products)', 'value': round(world * B * args.steps / dt1, 3),
+               'ms_per_step': round(dt1 / args.steps * 1e3, 3), 'steps': args.steps,
+               'step_frac_of_mfma_peak': round(world * B * args.steps / dt1 * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -479,7 +517,7 @@ def main():
         line = {
             'metric': 'training images/sec (216x216, x4)', 'value': round(value, 3), 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_LABEL[conv_math], 'data': 'synthetic',
             'spinup_steps': max(0, args.spinup_steps),
             'config': {'workload': 'SRADSGAN full GAN x4 training step (G+D+VGG perceptual, WGAN-GP), '
                                    'LR 54x54 -> HR 216x216, per-GPU batch %d' % B,
@@ -490,6 +528,9 @@ def main():
             'step_frac_of_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (MATH_PEAK[conv_math][0] * world), 4),
         }
         line['config']['conv_math'] = conv_math
+        if sync is not None:
+            line['rccl_ranks'] = sync.rccl_ranks()             # size of the communicator the gradients really went through
+            line['exchange'] = 'srhip_dp_allreduce_bucket on a dedicated HIP stream, G arena under the D step'
         if alt is not None:
             line['exact_fp32_mode'] = alt
         line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B)
@@ -497,6 +538,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
     if world > 1 or force_dist:
         dist.barrier()
+        sync.close()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio: flush that first so the JSON line is the last line

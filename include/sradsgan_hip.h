@@ -39,7 +39,9 @@ extern "C" {
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
 /* ABI 2: fast packed weights carry a second, pre-split bf16 section (srhip_packed_elems doubled for them);
- * srhip_set_conv_math / srhip_get_conv_math added. */
+ * srhip_set_conv_math / srhip_get_conv_math added.
+ * ABI 3: srhip_cgam_*, srhip_sgam_flash_*, loss reductions (srhip_l1_mean_*, srhip_mean_*, srhip_gp_norm_penalty_*),
+ * srhip_dp_* (RCCL gradient exchange) added. */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 register-staged kernels only, 21 no patch kernel, 1..8 fixed tile shapes of the register-staged kernel
@@ -160,6 +162,62 @@ int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, 
                             void* workspace, size_t workspace_bytes, int n, int c, int hidden, void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
+
+/* ---- global attention of GAB_UP (sradsgan.py:365-418), C == 64, NHWC [n][hw][64] ---------------- *
+ * CGAM (channel self-attention, sradsgan.py:178-213, light=False; call site :395): E = X^T X per image,
+ * A = softmax(rowmax(E) - E), y = gamma * (X A^T) + x.  Exact fp32 on the matrix pipe.  fwd saves A
+ * (att [n][64][64]); bwd returns dx (incl. the residual path) and dgamma (accumulate_dgamma != 0: +=).
+ * Both need srhip_cgam_workspace() bytes of scratch.                                                  */
+size_t srhip_cgam_workspace(int n, int hw);
+int srhip_cgam_fwd(const float* x, const float* gamma, float* y, float* att, void* workspace, size_t workspace_bytes,
+                   int n, int hw, int c, void* stream);
+int srhip_cgam_bwd(const float* dy, const float* x, const float* att, const float* gamma, float* dx, float* dgamma,
+                   int accumulate_dgamma, void* workspace, size_t workspace_bytes, int n, int hw, int c, void* stream);
+/* SGAM (position self-attention, sradsgan.py:153-176; call site :397) on already projected q, k [n][hw][8] and
+ * v [n][hw][64] (the 1x1 convs :157-159 are srhip_conv2d_fwd calls): y = gamma * softmax_j(q_i . k_j) v + x,
+ * no 1/sqrt(d) scaling.  Flash-style: the hw x hw energy / attention matrices (torch.bmm + Softmax, :167-172) are
+ * never written to memory; fwd saves o = softmax(.) v [n][hw][64] and the per-query log-sum-exp lse [n][hw];
+ * bwd recomputes the probabilities (deterministic two-pass, no atomics) and returns dq, dk, dv and dgamma; the
+ * gradient of the residual path is dy itself.  bwd needs srhip_sgam_flash_bwd_workspace() bytes.        */
+int srhip_sgam_flash_fwd(const float* q, const float* k, const float* v, const float* x, const float* gamma, float* y,
+                         float* o, float* lse, int n, int hw, int dk, int c, void* stream);
+size_t srhip_sgam_flash_bwd_workspace(int n, int hw);
+int srhip_sgam_flash_bwd(const float* dy, const float* q, const float* k, const float* v, const float* o, const float* lse,
+                         const float* gamma, float* dq, float* dk_out, float* dv, float* dgamma, int accumulate_dgamma,
+                         void* workspace, size_t workspace_bytes, int n, int hw, int dk, int c, void* stream);
+
+/* ---- loss reductions (deterministic two-stage sums; scalars stay on the device; every fwd needs
+ *      srhip_reduce_workspace() bytes of scratch; bwd kernels read the incoming scalar gradient from `gout`) --
+ * l1_mean:  nn.L1Loss() (sradsgan.py:686; pixel loss :834, content loss :838): out = mean |a - b|;
+ *           bwd: da = sign(a - b) * gout / count, db = -da when db != NULL.
+ * mean:     the WGAN critic means of GANLoss (sradsgan.py:61-66; :847, :876-878).
+ * gp_norm_penalty: sradsgan.py:630-637 with 'L2' / 'LS': per-pixel L2 norm over the C (<= 4) channels of
+ *           grads [npix][C], (norm - 1)^2, mean over pixels; bwd: d/dgrads (0 where the norm is 0, like torch). */
+size_t srhip_reduce_workspace(void);
+int srhip_l1_mean_fwd(const float* a, const float* b, float* out, void* workspace, size_t workspace_bytes, long count,
+                      void* stream);
+int srhip_l1_mean_bwd(const float* a, const float* b, const float* gout, float* da, float* db, long count, void* stream);
+int srhip_mean_fwd(const float* x, float* out, void* workspace, size_t workspace_bytes, long count, void* stream);
+int srhip_mean_bwd(const float* gout, float* dx, long count, void* stream);
+int srhip_gp_norm_penalty_fwd(const float* grads, float* out, void* workspace, size_t workspace_bytes, long npix, int c,
+                              void* stream);
+int srhip_gp_norm_penalty_bwd(const float* grads, const float* gout, float* dgrads, long npix, int c, void* stream);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI (the reference is single-GPU, README.md:91).
+ * One communicator per process = per GPU.  Rank 0 calls srhip_dp_unique_id and hands the srhip_dp_id_bytes() bytes
+ * to every rank (any side channel: the host code uses torch.distributed's store); every rank then calls
+ * srhip_dp_init with the current HIP device set.  srhip_dp_allreduce_bucket sums `count` floats in place over the
+ * ranks, asynchronously on `stream` (the caller orders it against compute with events and folds 1/world into
+ * srhip_adam_step's grad_scale); srhip_dp_broadcast makes replicas identical.  RCCL is bound with dlopen at the
+ * first call.                                                                                            */
+int srhip_dp_id_bytes(void);
+int srhip_dp_unique_id(void* id_out);
+int srhip_dp_init(const void* id_in, int rank, int world);
+int srhip_dp_world(void);
+int srhip_dp_rank(void);
+int srhip_dp_allreduce_bucket(float* buf, size_t count, void* stream);
+int srhip_dp_broadcast(float* buf, size_t count, int root, void* stream);
+int srhip_dp_finalize(void);
 
 /* ---- train-mode nn.BatchNorm2d + LeakyReLU (discriminator, sradsgan.py:478-479), NHWC [rows][C].
  * fwd: batch mean / biased variance -> y = act((x-mean)*invstd*gamma + beta); updates

@@ -46,6 +46,27 @@ SIGNATURES = {
     'srhip_attn_tail_mlp_workspace': (_sz, [_i, _i]),
     'srhip_attn_tail_bwd_mlp': (_i, [_vp] * 10 + [_i, _vp, _sz] + [_i] * 3 + [_vp]),
     'srhip_attn_tail_bwd_channel': (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    'srhip_cgam_workspace': (_sz, [_i, _i]),
+    'srhip_cgam_fwd': (_i, [_vp] * 5 + [_sz] + [_i] * 3 + [_vp]),
+    'srhip_cgam_bwd': (_i, [_vp] * 6 + [_i, _vp, _sz] + [_i] * 3 + [_vp]),
+    'srhip_sgam_flash_fwd': (_i, [_vp] * 8 + [_i] * 4 + [_vp]),
+    'srhip_sgam_flash_bwd_workspace': (_sz, [_i, _i]),
+    'srhip_sgam_flash_bwd': (_i, [_vp] * 11 + [_i, _vp, _sz] + [_i] * 4 + [_vp]),
+    'srhip_reduce_workspace': (_sz, []),
+    'srhip_l1_mean_fwd': (_i, [_vp] * 4 + [_sz, _l, _vp]),
+    'srhip_l1_mean_bwd': (_i, [_vp] * 5 + [_l, _vp]),
+    'srhip_mean_fwd': (_i, [_vp] * 3 + [_sz, _l, _vp]),
+    'srhip_mean_bwd': (_i, [_vp] * 2 + [_l, _vp]),
+    'srhip_gp_norm_penalty_fwd': (_i, [_vp] * 3 + [_sz, _l, _i, _vp]),
+    'srhip_gp_norm_penalty_bwd': (_i, [_vp] * 3 + [_l, _i, _vp]),
+    'srhip_dp_id_bytes': (_i, []),
+    'srhip_dp_unique_id': (_i, [_vp]),
+    'srhip_dp_init': (_i, [_vp, _i, _i]),
+    'srhip_dp_world': (_i, []),
+    'srhip_dp_rank': (_i, []),
+    'srhip_dp_allreduce_bucket': (_i, [_vp, _sz, _vp]),
+    'srhip_dp_broadcast': (_i, [_vp, _sz, _i, _vp]),
+    'srhip_dp_finalize': (_i, []),
     'srhip_bn_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_fwd': (_i, [_vp] * 9 + [_sz, _l, _i, _f, _f, _f, _i, _vp]),
     'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),

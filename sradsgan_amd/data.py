@@ -104,6 +104,31 @@ def calculate_valid_crop_size(crop_size, scale_factor):                         
     return crop_size - (crop_size % scale_factor)
 
 
+def rgb_train_dirs(data_dir, datasets):
+    """The class directories get_RGB_trainDataset walks (data/data.py:295-312): `SECOND` is one flat folder, AID / DOTA /
+    LoveDA / RSSCN7_2800 contribute every sub-directory (os.listdir order, like the reference); other names are ignored
+    there too."""
+    import os
+    dirs = []
+    for name in datasets:
+        if name == 'SECOND':
+            dirs.append(os.path.join(data_dir, name))
+        elif name in ('AID', 'DOTA', 'LoveDA', 'RSSCN7_2800'):
+            root = os.path.join(data_dir, name)
+            dirs.extend(os.path.join(root, d) for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+    return dirs
+
+
+def rgb_test_dirs(data_dir, datasets):
+    """get_RGB_testDataset's directory list (data/data.py:314-325): the sorted class folders of UCMerced_LandUse when that
+    is the first entry, otherwise the entries themselves are the directories."""
+    import os
+    if datasets and datasets[0] == 'UCMerced_LandUse':
+        root = os.path.join(data_dir, datasets[0])
+        return [os.path.join(root, d) for d in sorted(os.listdir(root)) if os.path.isdir(os.path.join(root, d))]
+    return list(datasets)
+
+
 class TileFolder:
     """The file side of RGB_TrainDatasetFromFolder / RGB_TestDatasetFromFolder (dataset.py:386-441): every image file of
     `image_dirs`, each directory's names sorted, directories in the order given; item i = (uint8 [H, W, 3] RGB tensor,

@@ -1,15 +1,14 @@
 """Data-parallel plumbing for the training step: flat parameter/gradient arenas and the gradient
 all-reduce.  The reference is single-GPU (README.md:91); this is the one exchange
 step the sharded path needs: one process per GPU, full replicas, mean of the G and D gradients over
-ranks before each Adam step.  Backend is whatever torch.distributed was initialised with -- "nccl"
-(= RCCL over xGMI) on MI355X, "gloo" in the CPU tests.
+ranks before each Adam step.  On MI355X the collectives are RCCL calls over xGMI through the C ABI
+(srhip_dp_*, include/sradsgan_hip.h) on their own HIP stream; torch.distributed provides the rendezvous
+(and, with "gloo", the whole exchange in the CPU tests).
 
 Layout: every network keeps ONE flat fp32 arena each for parameters, gradients and the two Adam
 moments (ParamArena).  Parameters and .grad tensors are views into the arenas, so
   * zero_grad is one memset, Adam(+clip) is one elementwise HIP kernel over the arena,
   * the all-reduce runs in place on contiguous arena slices (buckets) -- no flatten/unflatten copies.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): G's 44.3 MB and D's 18.8 MB of gradients are
-sent as <= 32 MiB buckets so the second bucket's reduce-scatter overlaps the first one's all-gather.
 """
 import torch
 import torch.distributed as dist
@@ -64,31 +63,120 @@ class ParamArena:
 
 
 class GradSync:
-    """Mean of a gradient arena over the ranks: bucketed in-place all-reduce(SUM), asynchronous per
-    bucket, then one scale by 1/world (folded into the Adam kernel by the caller when it can)."""
+    """The per-iteration gradient exchange and its ordering: `start(tag, flat)` launches the bucketed in-place
+    all-reduce(SUM) of a gradient arena as soon as its producers are enqueued, `finish(tag)` makes the consumer (the Adam
+    kernel of that network) wait for it; the 1/world of the mean is folded into the Adam kernel by the caller.
+
+    TrainStep calls start('G') right after the generator's backward is enqueued -- its gradients are final while the
+    whole discriminator step is still running, so the exchange flies under it --, start('D') after the discriminator's
+    backward (the second one, sradsgan.py:886; the first, :639, accumulates locally), and finish('G') / finish('D')
+    in front of the two Adam launches (:858, :887).
+
+    Device tensors: the collectives are RCCL calls through the C ABI (srhip_dp_allreduce_bucket, include/sradsgan_hip.h)
+    on a dedicated HIP stream; ordering against the compute streams is by events only, the host never synchronises.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): the arenas (G 44.3 MB, D 18.8 MB) go out as <= 32 MiB
+    buckets so the ring's reduce-scatter of one bucket overlaps the all-gather of the previous one.
+    CPU tensors (the gloo tests): the same object drives torch.distributed's asynchronous all_reduce.
+    """
 
     def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, force=False):
         self.group = group
         self.force = force           # run the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.trace = []              # ('start' | 'finish', tag): the order the step drove the exchange in (tests)
+        self._pending = {}           # tag -> event (device) or list of work handles (CPU)
+        self._comm_stream = None
+        self._rccl_ready = False
+
+    @property
+    def active(self):
+        return self.world > 1 or self.force
 
     def buckets(self, flat):
         n = flat.numel()
         return [flat[i:min(i + self.bucket_elems, n)] for i in range(0, n, self.bucket_elems)]
 
-    def start(self, flat):
-        """Launch the all-reduces; returns handles for finish().  `flat` must be the gradient arena
-        (contiguous 1-D).  With world == 1 this is a no-op."""
-        if self.world <= 1 and not self.force:
-            return []
-        if not dist.is_initialized():
-            raise RuntimeError('GradSync: torch.distributed is not initialised')
-        return [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets(flat)]
+    # ---- RCCL communicator behind the C ABI (device path) ------------------------------------------------------ #
+    def init_rccl(self, device=None):
+        """Creates this process's RCCL communicator (srhip_dp_init).  Rank 0 draws the unique id and hands it to the
+        other ranks through torch.distributed's rendezvous store (no collective, no second communicator needed)."""
+        if self._rccl_ready:
+            return
+        import ctypes
+        from . import _hip
+        lib = _hip.lib()
+        if device is not None:
+            torch.cuda.set_device(device)
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if lib.srhip_dp_world() == 0:
+            nbytes = lib.srhip_dp_id_bytes()
+            buf = ctypes.create_string_buffer(nbytes)
+            if world > 1:
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
+                    store.set('srhip_dp_unique_id', bytes(buf.raw))
+                else:
+                    raw = store.get('srhip_dp_unique_id')          # blocks until rank 0 has published it
+                    buf = ctypes.create_string_buffer(bytes(raw), nbytes)
+            else:
+                _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
+            _hip.check(lib.srhip_dp_init(buf, rank, world), 'dp_init')
+        if lib.srhip_dp_world() != world:
+            raise RuntimeError('GradSync: RCCL communicator has %d ranks, torch.distributed %d' % (lib.srhip_dp_world(), world))
+        self._comm_stream = torch.cuda.Stream()
+        self._rccl_ready = True
 
-    def finish(self, handles):
-        for h in handles:
-            h.wait()
+    def rccl_ranks(self):
+        from . import _hip
+        return _hip.lib().srhip_dp_world() if self._rccl_ready else 0
+
+    def close(self):
+        if self._rccl_ready:
+            from . import _hip
+            torch.cuda.synchronize()
+            _hip.check(_hip.lib().srhip_dp_finalize(), 'dp_finalize')
+            self._rccl_ready = False
+
+    # ---- the exchange -------------------------------------------------------------------------------------------- #
+    def start(self, tag, flat, after=()):
+        """Launch the all-reduce of arena `flat` under the name `tag`.  `after`: the HIP streams whose already enqueued
+        work produces `flat` (default: the current stream).  Returns immediately; with one rank (and not forced) a no-op."""
+        self.trace.append(('start', tag))
+        if not self.active:
+            return
+        if tag in self._pending:
+            raise RuntimeError('GradSync.start(%r): the previous exchange of this arena was never finished' % (tag,))
+        if flat.is_cuda:
+            import ctypes
+            from . import _hip
+            self.init_rccl(flat.device)
+            lib, comm = _hip.lib(), self._comm_stream
+            for s in (after or (torch.cuda.current_stream(),)):
+                comm.wait_stream(s)                                 # event record + wait: no host synchronisation
+            for b in self.buckets(flat):
+                _hip.check(lib.srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
+                                                         ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
+            self._pending[tag] = comm.record_event()
+        else:
+            if not dist.is_initialized():
+                raise RuntimeError('GradSync: torch.distributed is not initialised')
+            self._pending[tag] = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                                  for b in self.buckets(flat)]
+
+    def finish(self, tag):
+        """Order everything enqueued afterwards on the current stream behind the exchange `tag`."""
+        self.trace.append(('finish', tag))
+        pending = self._pending.pop(tag, None)
+        if pending is None:
+            return
+        if isinstance(pending, list):
+            for h in pending:
+                h.wait()
+        else:
+            torch.cuda.current_stream().wait_event(pending)
 
     @property
     def grad_scale(self):
@@ -96,7 +184,8 @@ class GradSync:
 
     def __call__(self, flat):
         """Synchronous convenience form: flat <- mean over ranks."""
-        self.finish(self.start(flat))
+        self.start('_sync', flat)
+        self.finish('_sync')
         if self.world > 1:
             flat.mul_(self.grad_scale)
         return flat

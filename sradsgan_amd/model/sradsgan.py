@@ -33,7 +33,7 @@ class GANLoss(nn.Module):
             raise NotImplementedError('GAN type [{:s}] is not found'.format(self.gan_type))
 
     def forward(self, input, target_is_real):
-        m = input.mean()
+        m = ops.mean(input)                       # srhip_mean_fwd: deterministic two-stage sum, result stays on the device
         return -m if target_is_real else m
 
 

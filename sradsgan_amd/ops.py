@@ -693,26 +693,98 @@ def slam(x, w7, pool_mode='Avg|Max'):
     return torch.sigmoid(conv2d(pooled, w7, None, 1, w7.shape[-1] // 2)) * x
 
 
+def _ws(nbytes, like):
+    return torch.empty((max(int(nbytes), 4) + 3) // 4, device=like.device, dtype=torch.float32)
+
+
+def _gamma_slot(gamma):
+    """(buffer, accumulate flag) for a scalar attention gamma: its arena slot in direct_param_grads() mode."""
+    g = _grad_slot(gamma)
+    if g is not None:
+        return g, 1
+    return torch.empty(1, device=gamma.device, dtype=torch.float32), 0
+
+
+class _Cgam(Function):
+    """Channel global attention, sradsgan.py:202-212 (srhip_cgam_fwd / srhip_cgam_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma):
+        _require_gpu(x, 'cgam')
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        lib = _hip.lib()
+        y = torch.empty_like(x, memory_format=CL)
+        att = torch.empty(n, c, c, device=x.device, dtype=torch.float32)
+        ws = _ws(lib.srhip_cgam_workspace(n, h * w), x)
+        gam = gamma.detach().reshape(1).contiguous()
+        _hip.check(lib.srhip_cgam_fwd(_p(x), _p(gam), _p(y), _p(att), _p(ws), ws.numel() * 4, n, h * w, c, _stream()),
+                   'cgam_fwd')
+        ctx.save_for_backward(x, att, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, att, gamma = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = x.shape
+        lib = _hip.lib()
+        dx = torch.empty_like(x, memory_format=CL)
+        skip = _skip_param_grads(gamma) or not ctx.needs_input_grad[1]
+        dgam, acc = (None, 0) if skip else _gamma_slot(gamma)
+        ws = _ws(lib.srhip_cgam_workspace(n, h * w), x)
+        gam = gamma.detach().reshape(1).contiguous()
+        _hip.check(lib.srhip_cgam_bwd(_p(dy), _p(x), _p(att), _p(gam), _p(dx), _p(dgam), acc, _p(ws), ws.numel() * 4,
+                                      n, h * w, c, _stream()), 'cgam_bwd')
+        return dx, (None if (skip or acc) else dgam.view(gamma.shape))
+
+
 def cgam(x, gamma):
     """sradsgan.py:202-212; softmax(rowmax(E)-E) == softmax(-E) (shift invariance)."""
-    b, c, h, w = x.shape
-    xf = x.permute(0, 2, 3, 1).reshape(b, h * w, c)            # NHWC memory: free view [b, n, c]
-    energy = xf.transpose(1, 2) @ xf                            # [b, c, c]
-    att = torch.softmax(energy.max(dim=-1, keepdim=True)[0] - energy, dim=-1)
-    out = xf @ att.transpose(1, 2)                              # [b, n, c]
-    return gamma * out.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+    return _Cgam.apply(x, gamma)
+
+
+class _SgamCore(Function):
+    """Position global attention on projected q, k, v (sradsgan.py:165-175): flash-style, no N x N tensor
+    (srhip_sgam_flash_fwd / srhip_sgam_flash_bwd).  Saves q, k, v, o = softmax(qk^T) v and the per-query
+    log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, x, q, k, v, gamma):
+        _require_gpu(x, 'sgam')
+        x, q, k, v = nhwc(x), nhwc(q), nhwc(k), nhwc(v)
+        n, c, h, w = x.shape
+        lib = _hip.lib()
+        y = torch.empty_like(x, memory_format=CL)
+        o = torch.empty_like(x, memory_format=CL)
+        lse = torch.empty(n, h * w, device=x.device, dtype=torch.float32)
+        gam = gamma.detach().reshape(1).contiguous()
+        _hip.check(lib.srhip_sgam_flash_fwd(_p(q), _p(k), _p(v), _p(x), _p(gam), _p(y), _p(o), _p(lse), n, h * w,
+                                            q.shape[1], c, _stream()), 'sgam_flash_fwd')
+        ctx.save_for_backward(q, k, v, o, lse, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, k, v, o, lse, gamma = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = v.shape
+        lib = _hip.lib()
+        dq, dk = torch.empty_like(q, memory_format=CL), torch.empty_like(k, memory_format=CL)
+        dv = torch.empty_like(v, memory_format=CL)
+        skip = _skip_param_grads(gamma) or not ctx.needs_input_grad[4]
+        dgam, acc = (None, 0) if skip else _gamma_slot(gamma)
+        ws = _ws(lib.srhip_sgam_flash_bwd_workspace(n, h * w), v)
+        gam = gamma.detach().reshape(1).contiguous()
+        _hip.check(lib.srhip_sgam_flash_bwd(_p(dy), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(gam), _p(dq), _p(dk), _p(dv),
+                                            _p(dgam), acc, _p(ws), ws.numel() * 4, n, h * w, q.shape[1], c, _stream()),
+                   'sgam_flash_bwd')
+        return dy, dq, dk, dv, (None if (skip or acc) else dgam.view(gamma.shape))
 
 
 def sgam(x, q, k, v, gamma):
-    """sradsgan.py:165-175 with q,k,v already projected (NHWC memory). Materialises N x N for now."""
-    b, c, h, w = x.shape
-    n = h * w
-    qf = q.permute(0, 2, 3, 1).reshape(b, n, -1)
-    kf = k.permute(0, 2, 3, 1).reshape(b, n, -1)
-    vf = v.permute(0, 2, 3, 1).reshape(b, n, c)
-    att = torch.softmax(qf @ kf.transpose(1, 2), dim=-1)        # [b, n(query), n(key)]
-    out = att @ vf                                              # [b, n, c]
-    return gamma * out.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+    """sradsgan.py:165-175 with q, k, v already projected by the 1x1 convs (:157-159)."""
+    return _SgamCore.apply(x, q, k, v, gamma)
 
 
 def _bn_reference_bwd(dy, x, y, gamma, eps, slope):
@@ -911,11 +983,85 @@ def vgg_features(x, weights_and_biases):
     return _VggFeatures.apply(x, *weights_and_biases)
 
 
+class _L1Mean(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, 'l1_mean')
+        a = nhwc(a) if a.dim() == 4 else a.contiguous()
+        b = b.contiguous(memory_format=CL) if (b.dim() == 4) else b.contiguous()
+        if a.shape != b.shape:
+            raise ValueError('l1_mean: shapes differ: %s vs %s' % (tuple(a.shape), tuple(b.shape)))
+        lib = _hip.lib()
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = _ws(lib.srhip_reduce_workspace(), a)
+        _hip.check(lib.srhip_l1_mean_fwd(_p(a), _p(b), _p(out), _p(ws), ws.numel() * 4, a.numel(), _stream()), 'l1_mean_fwd')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad
+        da = torch.empty_like(a, memory_format=CL) if a.dim() == 4 else torch.empty_like(a)
+        db = (torch.empty_like(a, memory_format=CL) if a.dim() == 4 else torch.empty_like(a)) if need_b else None
+        _hip.check(_hip.lib().srhip_l1_mean_bwd(_p(a), _p(b), _p(gout.contiguous()), _p(da), _p(db), a.numel(), _stream()),
+                   'l1_mean_bwd')
+        return (da if need_a else None), db
+
+
 def l1_mean(a, b):
     """nn.L1Loss() (sradsgan.py:686,834,838)."""
-    return (a - b).abs().mean()
+    return _L1Mean.apply(a, b)
+
+
+class _Mean(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, 'mean')
+        xc = x.contiguous()
+        lib = _hip.lib()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = _ws(lib.srhip_reduce_workspace(), x)
+        _hip.check(lib.srhip_mean_fwd(_p(xc), _p(out), _p(ws), ws.numel() * 4, xc.numel(), _stream()), 'mean_fwd')
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        dx = torch.empty(ctx.shape, device=gout.device, dtype=torch.float32)
+        _hip.check(_hip.lib().srhip_mean_bwd(_p(gout.contiguous()), _p(dx), dx.numel(), _stream()), 'mean_bwd')
+        return dx
+
+
+def mean(x):
+    """The critic means of GANLoss('wgan-gp') (sradsgan.py:61-66)."""
+    return _Mean.apply(x)
+
+
+class _GpPenalty(Function):
+    @staticmethod
+    def forward(ctx, grads):
+        _require_gpu(grads, 'gp_penalty')
+        g = nhwc(grads)
+        n, c, h, w = g.shape
+        lib = _hip.lib()
+        out = torch.empty((), device=g.device, dtype=torch.float32)
+        ws = _ws(lib.srhip_reduce_workspace(), g)
+        _hip.check(lib.srhip_gp_norm_penalty_fwd(_p(g), _p(out), _p(ws), ws.numel() * 4, n * h * w, c, _stream()),
+                   'gp_norm_penalty_fwd')
+        ctx.save_for_backward(g)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        n, c, h, w = g.shape
+        dg = torch.empty_like(g, memory_format=CL)
+        _hip.check(_hip.lib().srhip_gp_norm_penalty_bwd(_p(g), _p(gout.contiguous()), _p(dg), n * h * w, c, _stream()),
+                   'gp_norm_penalty_bwd')
+        return dg
 
 
 def gp_penalty(grads):
     """sradsgan.py:630-637: L2 norm over the channel dim (per pixel), LS penalty, mean."""
-    return (grads.norm(2, 1) - 1).pow(2).mean()
+    return _GpPenalty.apply(grads)

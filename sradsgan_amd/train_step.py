@@ -7,7 +7,9 @@ Structure (MI355X-first, not the reference's call order):
               once into a hipGraph and replayed per iteration (the step is ~7000 launches; replay
               removes the host from the critical path).
   exchange  = in-place bucketed all-reduce of the G and D gradient arenas over RCCL (only with
-              world_size > 1; sradsgan_amd/dp.py).
+              world_size > 1; sradsgan_amd/dp.py GradSync) on its own HIP stream: G's arena is sent as soon as
+              the generator's backward is enqueued and travels under the whole discriminator step, D's after
+              the discriminator's backward; the two Adam launches wait on the matching events.
   update    = one fused Adam kernel per network over its flat arena (srhip_adam_step), the D one
               also applying the weight clip (:891-892).
 
@@ -56,6 +58,7 @@ class TrainStep:
         self._d_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
+        self._capturing = False
         self._calls = 0
         self._static = None
         self._d_params = self.arena_D.params
@@ -89,14 +92,15 @@ class TrainStep:
         with torch.no_grad():
             real_feat = F(imgs_hr)
         content = ops.l1_mean(F(gen_hr), real_feat)
-        loss_gan = -D(gen_hr).mean()
+        loss_gan = -ops.mean(D(gen_hr))
         loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
         loss_G.backward()
+        self._exchange_start('G')
         # ---------------- discriminator (sradsgan.py:865-886) ----------------
         self._set_d_grad(True)
         self.arena_D.zero_grad()
         fake = gen_hr.detach()
-        loss_D = -D(imgs_hr).mean() + D(fake).mean()
+        loss_D = -ops.mean(D(imgs_hr)) + ops.mean(D(fake))
         if self.use_gp:
             gp = self.gradient_penalty(imgs_hr, fake, alpha)
             total = loss_D + (1.0 + self.lambda_gp) * gp          # :639 + :884-886 => 1 + lambda
@@ -105,8 +109,21 @@ class TrainStep:
             gp = torch.zeros((), device=imgs_hr.device)
             total = loss_D
         total.backward()
+        self._exchange_start('D')
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+
+    def _exchange_start(self, which):
+        """Hands a finished gradient arena to the exchange (dp.GradSync.start): called right after the backward that
+        completes it has been ENQUEUED; the collective waits on events of the streams that produce the arena."""
+        gs = self.grad_sync
+        if gs is None or not gs.active or self._capturing:
+            return
+        arena = self.arena_G if which == 'G' else self.arena_D
+        streams = [torch.cuda.current_stream()] if arena.flat_g.is_cuda else []
+        if arena.flat_g.is_cuda and self.overlap_wgrad and not self.use_graph and self._wgrad_stream is not None:
+            streams.append(self._wgrad_stream)                    # the weight-gradient kernels run there
+        gs.start(which, arena.flat_g, after=streams)
 
     def _compute_shared(self, imgs_lr, imgs_hr, alpha):
         """Same arithmetic, one discriminator forward fewer: D(gen_hr) of the G step (:847) and
@@ -142,12 +159,12 @@ class TrainStep:
         d_gen = D(gen_hr)                                         # running-stat update #1
         for bn in self._bns:
             bn._stat_stash = None
-        loss_gan = -d_gen.mean()
+        loss_gan = -ops.mean(d_gen)
         loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
 
         def d_forward():
             # ---------------- discriminator forward passes (sradsgan.py:865-884) ----------------
-            loss_D = -D(imgs_hr).mean() + d_gen.mean()            # update #2 (real)
+            loss_D = -ops.mean(D(imgs_hr)) + ops.mean(d_gen)      # update #2 (real)
             ops.replay_bn_update(stash)                           # update #3 (the fake pass that is not recomputed)
             fake = gen_hr.detach()
             if self.use_gp:
@@ -173,6 +190,7 @@ class TrainStep:
                 t.record_stream(dside)
             with ops.backward_scope(skip_params=d_params):        # no discriminator wgrads in the G step (:857 -> :865)
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+            self._exchange_start('G')                             # G's gradients travel under the whole D step
             with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
                 torch.autograd.backward(total, inputs=d_params)
             main.wait_stream(dside)
@@ -182,9 +200,11 @@ class TrainStep:
         else:
             with ops.backward_scope(skip_params=d_params):
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+            self._exchange_start('G')
             loss_D, gp, total, fake = d_forward()
             with ops.backward_scope(stop_at=(gen_hr,)):
                 torch.autograd.backward(total, inputs=d_params)
+        self._exchange_start('D')
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
 
@@ -196,19 +216,20 @@ class TrainStep:
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'adam_step')
 
     def _update(self):
-        """exchange + update: sradsgan.py:858 (optimizer_G.step), :887 (optimizer_D.step), :891-892 (clip)."""
+        """exchange + update: sradsgan.py:858 (optimizer_G.step), :887 (optimizer_D.step), :891-892 (clip).
+        The all-reduces were launched from _compute (or are launched here when the compute part is a replayed
+        hipGraph); each Adam kernel waits for its arena's exchange through a stream event -- no host synchronise."""
+        gs = self.grad_sync
         scale = 1.0
-        if self.grad_sync is not None and (self.grad_sync.world > 1 or getattr(self.grad_sync, 'force', False)):
-            if os.environ.get('SRHIP_DP_HOST_SYNC', '1') == '1':
-                # Enqueue the collectives only once the GPU has actually finished the backward pass.  Measured on
-                # MI355X / ROCm 7.2 / RCCL 2.26: an all-reduce enqueued ~100 ms ahead of its inputs (a wait on the
-                # compute stream parked at the head of RCCL's queue) slows the whole queued step by 8-56 ms even
-                # for a 64-byte payload; with the host sync the exchange costs what the wire costs.
-                torch.cuda.current_stream().synchronize()
-            handles = self.grad_sync.start(self.arena_G.flat_g) + self.grad_sync.start(self.arena_D.flat_g)
-            self.grad_sync.finish(handles)
-            scale = self.grad_sync.grad_scale
+        if gs is not None and gs.active:
+            if self.use_graph and self._graph is not None:
+                gs.start('G', self.arena_G.flat_g)
+                gs.start('D', self.arena_D.flat_g)
+            scale = gs.grad_scale
+            gs.finish('G')
         self._adam(self.arena_G, self.lr_G, 0.0, scale)
+        if gs is not None and gs.active:
+            gs.finish('D')
         self._adam(self.arena_D, self.lr_D, self.clip_value, scale)
         ops.bump_weight_epoch()
 
@@ -219,8 +240,12 @@ class TrainStep:
         dump = os.environ.get('SRHIP_GRAPH_DUMP')
         if dump:
             self._graph.enable_debug_mode()
-        with torch.cuda.graph(self._graph):
-            self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
+        self._capturing = True
+        try:
+            with torch.cuda.graph(self._graph):
+                self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
+        finally:
+            self._capturing = False
         if dump:
             self._graph.debug_dump(dump)
 

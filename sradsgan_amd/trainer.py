@@ -5,11 +5,13 @@ keeps working with the import changed.  Same argparse field nam
 (main_sradsgan.py:16-61, `default_args`), same loss weights / optimiser settings / step order (TrainStep), same
 checkpoint names and log lines, same epoch control (PlateauRollback).
 
-What differs, on purpose: the data side.  The reference builds folder datasets with 16 PIL workers
-(`load_dataset`, :560-593); this class takes the batches from an iterable the caller injects (`train_loader`,
-`test_loader`) -- either the reference's own DataLoader (tuples `(lr, hr, bc, paths)` of float tensors) or uint8 HR
-tiles `[N, H, W, 3]`, which are turned into (lr, hr, bc) on the device (sradsgan_amd.data.training_batch, bit-exact with
-the PIL path).  Metrics are computed on the device (validate.py); LPIPS is not reproduced (AlexNet weights are a
+The data side: like the reference (`load_dataset`, sradsgan.py:643-656) the trainer builds its loaders from
+`args.data_dir / train_dataset / test_dataset` when none are injected -- the same directory walk and file order
+(data/data.py:295-346), but as `data.TileFolder` + `data.DevicePrefetcher`: uint8 HR tiles decoded by worker threads,
+copied on their own HIP stream, and turned into (lr, hr, bc) on the device (sradsgan_amd.data.training_batch /
+test_batch, bit-exact with the reference's PIL transforms) instead of 16 PIL worker processes.  An injected iterable
+(`train_loader`, `test_loader`: the reference's own DataLoader tuples `(lr, hr, bc, paths)` or uint8 HR tiles
+`[N, H, W, 3]`) takes precedence.  Metrics are computed on the device (validate.py); LPIPS is not reproduced (AlexNet weights are a
 download): the lpips slots of the returned tuples and log lines carry NaN.  PNG panels are not written."""
 import argparse
 import math
@@ -137,11 +139,34 @@ class SRADSGAN(object):
         lr, hr, bc = item[0], item[1], item[2]
         return lr.to(self.device).float(), hr.to(self.device).float(), bc.to(self.device).float()
 
+    # ------------------------------------------------------------------ datasets ---------------- #
+    def load_dataset(self, dataset='train', max_samples=20000, dirs=None):
+        """sradsgan.py:643-656: DataLoader(shuffle=True, drop_last=True) over the training folders resp.
+        DataLoader(shuffle=False, drop_last=True) over the test folders of `args.data_dir`, as a device prefetcher of
+        uint8 tiles.  `dirs` overrides the directory list (per-class validation)."""
+        if self.num_channels == 1:
+            raise NotImplementedError('load_dataset: RGB tiles only (num_channels=3 is what main_sradsgan.py passes)')
+        if dataset == 'train':
+            print('Loading train dct_datasets...')
+            folders = sdata.rgb_train_dirs(self.data_dir, self.train_dataset) if dirs is None else dirs
+            tiles = sdata.TileFolder(folders, crop_size=self.crop_size, scale_factor=self.scale_factor)
+            return sdata.DevicePrefetcher(tiles, self.batch_size, self.device, shuffle=True, drop_last=True,
+                                          num_workers=self.num_threads, rank=self.rank, world=self.world)
+        if dataset == 'test':
+            print('Loading test dct_datasets...')
+            folders = sdata.rgb_test_dirs(self.data_dir, self.test_dataset) if dirs is None else dirs
+            tiles = sdata.TileFolder(folders, crop_size=self.crop_size, scale_factor=self.scale_factor)
+            return sdata.DevicePrefetcher(tiles, self.test_batch_size, self.device, shuffle=False, drop_last=True,
+                                          num_workers=self.num_threads)
+        raise ValueError("load_dataset: dataset must be 'train' or 'test'")
+
     # ------------------------------------------------------------------ training ---------------- #
     def train(self):
         """sradsgan.py:658-1036.  Returns the per-epoch history (avg losses and validation metrics)."""
         if self.train_loader is None:
-            raise ValueError('SRADSGAN.train: inject train_loader (the folder datasets of the reference are not rebuilt)')
+            self.train_loader = self.load_dataset(dataset='train', max_samples=self.max_train_samples)    # :749
+        if self.test_loader is None:
+            self.test_loader = self.load_dataset(dataset='test')                                          # :750
         os.makedirs(self.save_dir, exist_ok=True)
         self._build()
         model_dir = os.path.join(self.save_dir, 'model')
@@ -194,9 +219,10 @@ class SRADSGAN(object):
 
     # ------------------------------------------------------------------ validation -------------- #
     def _evaluate_loader(self, generator, label, loader=None, totals=None):
-        loader = self.test_loader if loader is None else loader
         if loader is None:
-            raise ValueError('SRADSGAN.validate: inject test_loader')
+            if self.test_loader is None:
+                self.test_loader = self.load_dataset(dataset='test')                              # :1074, :1277
+            loader = self.test_loader
         sums = {k: 0.0 for k in ('bicubic_mse', 'bicubic_psnr', 'bicubic_ssim', 'bicubic_ergas', label + '_mse', label + '_psnr',
                                  label + '_ssim', label + '_ergas')}
         img_num = 0
@@ -251,12 +277,15 @@ class SRADSGAN(object):
 
     def mfeNew_validateByClass(self, epoch, save_img=False, modelpath=None):
         """sradsgan.py:1393-1601: the validation of mfeNew_validate once per class folder of the test set, one
-        `val_log.txt` line per class (model = class name) and a final "Total" line over all images.  The reference
-        builds one DataLoader per UCMerced class directory (:1433-1447); here `self.class_loaders` (an ordered mapping
-        class name -> iterable of batches) is injected like the other loaders.  Returns {class or 'Total': averages}."""
+        `val_log.txt` line per class (model = class name) and a final "Total" line over all images.  Like the
+        reference one loader per class directory of the test set is built (:1433-1447) unless `self.class_loaders` (an
+        ordered mapping class name -> iterable of batches) was injected.  Returns {class or 'Total': averages}."""
         loaders = getattr(self, 'class_loaders', None)
-        if not loaders:
-            raise ValueError('SRADSGAN.mfeNew_validateByClass: inject class_loaders (class name -> loader)')
+        if not loaders:                                                                          # :1430-1447
+            loaders = OrderedDict()
+            for d in sdata.rgb_test_dirs(self.data_dir, self.test_dataset):
+                loaders[os.path.split(d)[-1]] = self.load_dataset(dataset='test', dirs=[d])
+                print('Number of val images in [{:s}]: {:d}'.format(d, len(loaders[os.path.split(d)[-1]])))
         self.generator = self._new_generator().to(self.device)
         if modelpath is not None:
             self.generator.load_state_dict(torch.load(modelpath, map_location='cpu'), strict=False)   # :1400-1401

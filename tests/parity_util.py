@@ -134,6 +134,26 @@ def train_parity(device, tag, n_groups, n_blocks, batch, lr_side, scale, iters, 
     return worst, gscore
 
 
+def weight_quantiles(hip_nets, ora_nets, tol=2e-5):
+    """Post-step weights, HIP vs oracle, over every floating-point parameter (running statistics excluded): the
+    fraction of elements within `tol`, the worst element and the worst tensor.  Adam's first steps are ~lr * sign(g),
+    so an element whose gradient is roundoff-sized on both sides may legitimately differ by up to 2 * lr per step; the
+    fraction says how many do (measured on the oracle itself, fp32 vs fp64: ~1e-4 of the elements)."""
+    tot = within = 0
+    worst, worst_key = 0.0, ''
+    for hn, on in zip(hip_nets, ora_nets):
+        osd = on.state_dict()
+        for k, a in hn.state_dict().items():
+            if not a.dtype.is_floating_point or 'running_' in k:
+                continue
+            d = (a.detach().cpu().double() - osd[k].detach().cpu().double()).abs()
+            tot += d.numel()
+            within += int((d <= tol).sum())
+            if float(d.max()) > worst:
+                worst, worst_key = float(d.max()), k
+    return {'frac_within': within / max(tot, 1), 'max': worst, 'worst_tensor': worst_key, 'elements': tot}
+
+
 def sibling_grad_check(net, golden, ref32, ref64, run_case, rtol=1e-3, wiring=5e-2, tie_eps=2e-6):
     """Gradient criterion for the sibling generators (EDSR / SRGAN / SRAGAN tests).  `net` holds the HIP gradients of
     `run_case`.  A tensor passes when it is within `rtol` of the reference-recorded digest (scale max(1, |g|max)) OR

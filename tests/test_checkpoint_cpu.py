@@ -97,3 +97,19 @@ def test_val_log_line_format(tmp_path):
     validate.append_log(str(p), 'val', rlt)
     validate.append_log(str(p), 'val', rlt)
     assert p.read_text().count('\n') == 2 and 'epoch' in rlt
+
+
+def test_dataset_directory_walk_matches_the_reference(tmp_path):
+    """data.rgb_train_dirs / rgb_test_dirs restate get_RGB_trainDataset / get_RGB_testDataset's directory lists
+    (data/data.py:295-325): SECOND flat, the four class-folder datasets expanded, unknown names ignored, UCMerced's
+    class folders sorted, other test entries taken as directories themselves."""
+    import os
+    from sradsgan_amd import data as D
+    for d in ('AID/b', 'AID/a', 'SECOND', 'DOTA/x', 'Other/z', 'UCMerced_LandUse/river', 'UCMerced_LandUse/beach'):
+        os.makedirs(os.path.join(str(tmp_path), d))
+    open(os.path.join(str(tmp_path), 'AID', 'readme.txt'), 'w').close()
+    got = D.rgb_train_dirs(str(tmp_path), ['AID', 'SECOND', 'Other', 'DOTA'])
+    assert sorted(got[:2]) == [os.path.join(str(tmp_path), 'AID', 'a'), os.path.join(str(tmp_path), 'AID', 'b')]
+    assert got[2:] == [os.path.join(str(tmp_path), 'SECOND'), os.path.join(str(tmp_path), 'DOTA', 'x')]
+    assert D.rgb_test_dirs(str(tmp_path), ['UCMerced_LandUse']) == [os.path.join(str(tmp_path), 'UCMerced_LandUse', c) for c in ('beach', 'river')]
+    assert D.rgb_test_dirs(str(tmp_path), ['/some/dir']) == ['/some/dir']

@@ -48,6 +48,82 @@ def test_gradsync_mean_world2(tmp_path):
     assert [open(os.path.join(str(tmp_path), 'ok%d' % r)).read() for r in range(2)] == ['1', '1']
 
 
+def _order_worker(rank, world, port, out_dir):
+    """The ordering TrainStep drives (train_step.TrainStep._exchange_start / _update) on the object it uses (dp.GradSync):
+    the G arena goes out after the generator's backward and is in flight while the D step computes, the D arena after
+    the discriminator's backward; each Adam waits for its own arena only."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sradsgan_amd.dp import GradSync, ParamArena, broadcast_module
+    torch.manual_seed(7)
+    netG = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(8, 3, 3))
+    netD = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 1, 3))
+    broadcast_module(netG, 0), broadcast_module(netD, 0)
+    aG, aD = ParamArena(netG), ParamArena(netD)
+    sync = GradSync(world, bucket_bytes=512)
+    torch.manual_seed(50 + rank)
+    x = torch.randn(2, 3, 12, 12)
+    netG(x).abs().mean().backward()                        # "generator backward"
+    localG = aG.flat_g.clone()
+    sync.start('G', aG.flat_g)                             # TrainStep._exchange_start('G')
+    try:
+        sync.start('G', aG.flat_g)                         # a second start before finish is a bug in the caller
+        dup = False
+    except RuntimeError:
+        dup = True
+    netD(x).mean().backward()                              # "discriminator step" while G's buckets travel
+    localD = aD.flat_g.clone()
+    sync.start('D', aD.flat_g)                             # TrainStep._exchange_start('D')
+    sync.finish('G')                                       # TrainStep._update: before Adam(G)
+    gG = [torch.empty_like(localG) for _ in range(world)]
+    dist.all_gather(gG, localG)
+    ok = dup and torch.allclose(aG.flat_g * sync.grad_scale, sum(gG) / world, rtol=1e-6, atol=1e-7)
+    sync.finish('D')                                       # before Adam(D)
+    gD = [torch.empty_like(localD) for _ in range(world)]
+    dist.all_gather(gD, localD)
+    ok = ok and torch.allclose(aD.flat_g * sync.grad_scale, sum(gD) / world, rtol=1e-6, atol=1e-7)
+    ok = ok and sync.trace == [('start', 'G'), ('start', 'G'), ('start', 'D'), ('finish', 'G'), ('finish', 'D')]
+    ok = ok and not sync._pending
+    open(os.path.join(out_dir, 'ord%d' % rank), 'w').write('1' if ok else '0')
+    dist.destroy_process_group()
+
+
+def test_exchange_ordering_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_order_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), 'ord%d' % r)).read() for r in range(2)] == ['1', '1']
+
+
+def test_train_step_drives_the_exchange_in_that_order():
+    """TrainStep's own call sequence, checked without a GPU: _exchange_start / _update call GradSync.start('G'),
+    start('D'), finish('G'), finish('D') in this order (a recording stand-in replaces the arenas and kernels)."""
+    import types
+    from sradsgan_amd import train_step as ts
+    from sradsgan_amd.dp import GradSync
+    calls = []
+    sync = GradSync(2)
+    sync.start = lambda tag, flat, after=(): calls.append(('start', tag))
+    sync.finish = lambda tag: calls.append(('finish', tag))
+    step = ts.TrainStep.__new__(ts.TrainStep)
+    step.grad_sync, step._capturing, step.use_graph, step._graph = sync, False, False, None
+    step.overlap_wgrad, step._wgrad_stream = False, None
+    step.arena_G = types.SimpleNamespace(flat_g=torch.zeros(4))
+    step.arena_D = types.SimpleNamespace(flat_g=torch.zeros(4))
+    step.lr_G = step.lr_D = 1e-4
+    step.clip_value = 0.01
+    step._adam = lambda arena, lr, clip, scale: calls.append(('adam', 'G' if arena is step.arena_G else 'D', scale))
+    orig = ts.ops.bump_weight_epoch
+    ts.ops.bump_weight_epoch = lambda: None
+    try:
+        step._exchange_start('G')
+        step._exchange_start('D')
+        step._update()
+    finally:
+        ts.ops.bump_weight_epoch = orig
+    assert calls == [('start', 'G'), ('start', 'D'), ('finish', 'G'), ('adam', 'G', 0.5), ('finish', 'D'), ('adam', 'D', 0.5)]
+
+
 def _control_worker(rank, world, port, out_dir):
     """The trainer's data-parallel control plane (sradsgan_amd/trainer.py under torch.distributed): rank 0's validation
     numbers reach every rank (NaN included), so every rank replays the same PlateauRollback sequence; shards of one

@@ -120,3 +120,39 @@ def test_unsupported_reference_options_fail_loudly():
     from sradsgan_amd import trainer as T
     with pytest.raises(NotImplementedError):
         T.SRADSGAN(T.default_args(penalty_type='hinge'))
+
+
+def _write_tiles(folder, n, size, seed):
+    import numpy as np
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        Image.fromarray(rng.randint(0, 256, (size, size, 3), dtype=np.uint8)).save(os.path.join(folder, 'tile_%02d.png' % i))
+
+
+def test_drop_in_train_from_data_dir_without_injected_loaders(tmp_path):
+    """`net = SRADSGAN(args); net.train(); net.mfeNew_validate(...)` exactly as main_sradsgan.py:116-135 calls them: the
+    loaders come from args.data_dir / train_dataset / test_dataset (sradsgan.py:643-656, data/data.py:295-346)."""
+    from sradsgan_amd import trainer as T
+    data = tmp_path / 'dataset'
+    _write_tiles(str(data / 'AID' / 'Airport'), 3, 32, 1)
+    _write_tiles(str(data / 'AID' / 'Beach'), 2, 32, 2)
+    _write_tiles(str(data / 'SECOND'), 2, 32, 3)
+    _write_tiles(str(data / 'UCMerced_LandUse' / 'agricultural'), 2, 32, 4)
+    _write_tiles(str(data / 'UCMerced_LandUse' / 'airplane'), 1, 32, 5)
+    args = T.default_args(scale_factor=4, num_epochs=1, batch_size=2, test_batch_size=1, save_dir=str(tmp_path / 'Result'),
+                          data_dir=str(data), train_dataset=['AID', 'SECOND'], test_dataset=['UCMerced_LandUse'], crop_size=32,
+                          hr_height=32, hr_width=32, sample_interval=1, num_threads=2, n_residual_blocks=1, n_basic_blocks=1)
+    net = T.SRADSGAN(args)                                   # no loaders injected
+    hist = net.train()
+    assert len(net.train_loader) == 3 and len(net.test_loader) == 3          # 7 training tiles // 2, 3 test tiles
+    assert len(hist) == 1 and all(v == v for v in (hist[0]['loss_G'], hist[0]['loss_D'], hist[0]['psnr']))
+    model = os.path.join(str(tmp_path / 'Result'), 'model', 'generator_param_epoch_1.pkl')
+    net2 = T.SRADSGAN(args)
+    psnr, ssim, ergas, lpips = net2.mfeNew_validate(epoch=1, modelpath=model)
+    assert abs(psnr - hist[0]['psnr']) < 1e-9 and lpips != lpips
+    by_class = net2.mfeNew_validateByClass(epoch=1, modelpath=model)
+    assert list(by_class.keys()) == ['agricultural', 'airplane', 'Total']
+    tot = (2 * by_class['agricultural']['sradsgan_psnr'] + by_class['airplane']['sradsgan_psnr']) / 3
+    assert abs(tot - by_class['Total']['sradsgan_psnr']) < 1e-9 and abs(by_class['Total']['sradsgan_psnr'] - psnr) < 1e-9
