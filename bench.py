@@ -458,6 +458,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get('BENCH_MAIN_STREAM') == '1':              # experiment: the step on a non-default (non-blocking) stream
+        torch.cuda.set_stream(torch.cuda.Stream())
     trace = []
     for _ in range(max(0, args.spinup_steps)):                  # untimed, before the contract's W warm-up steps
         step(lr, hr, alpha)

@@ -126,7 +126,12 @@ class GradSync:
             _hip.check(lib.srhip_dp_init(buf, rank, world), 'dp_init')
         if lib.srhip_dp_world() != world:
             raise RuntimeError('GradSync: RCCL communicator has %d ranks, torch.distributed %d' % (lib.srhip_dp_world(), world))
-        self._comm_stream = torch.cuda.Stream()
+        import os
+        # HIGH priority: the exchange is enqueued tens of milliseconds ahead of its inputs, i.e. its stream sits on an
+        # event wait for most of the step.  Measured on MI355X / ROCm 7.2 (single rank, tools/gpu_r2_dist.sh): parked on
+        # a normal-priority queue that wait slows the compute streams' kernels by 12 % (75.1 vs 66.6 ms per step, with or
+        # without an RCCL call behind it); on a high-priority queue the step costs 66.9 ms (+0.4 %).
+        self._comm_stream = torch.cuda.Stream(priority=0 if os.environ.get('SRHIP_DP_PRIO') == '0' else -1)
         self._rccl_ready = True
 
     def rccl_ranks(self):
@@ -156,9 +161,14 @@ class GradSync:
             lib, comm = _hip.lib(), self._comm_stream
             for s in (after or (torch.cuda.current_stream(),)):
                 comm.wait_stream(s)                                 # event record + wait: no host synchronisation
-            for b in self.buckets(flat):
-                _hip.check(lib.srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
-                                                         ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
+            import os
+            if os.environ.get('SRHIP_DP_MODE') == 'fake':           # experiment: same stream / event structure, no RCCL call
+                with torch.cuda.stream(comm):
+                    flat[:64].mul_(1.0)
+            else:
+                for b in self.buckets(flat):
+                    _hip.check(lib.srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
+                                                             ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
             self._pending[tag] = comm.record_event()
         else:
             if not dist.is_initialized():
