@@ -41,7 +41,7 @@ int srhip_abi_version(void);
 /* ABI 2: fast packed weights carry a second, pre-split bf16 section (srhip_packed_elems doubled for them);
  * srhip_set_conv_math / srhip_get_conv_math added.
  * ABI 3: srhip_cgam_*, srhip_sgam_flash_*, loss reductions (srhip_l1_mean_*, srhip_mean_*, srhip_gp_norm_penalty_*),
- * srhip_dp_* (RCCL gradient exchange) added. */
+ * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added. */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 register-staged kernels only, 21 no patch kernel, 1..8 fixed tile shapes of the register-staged kernel
@@ -185,6 +185,28 @@ size_t srhip_sgam_flash_bwd_workspace(int n, int hw);
 int srhip_sgam_flash_bwd(const float* dy, const float* q, const float* k, const float* v, const float* o, const float* lse,
                          const float* gamma, float* dq, float* dk_out, float* dv, float* dgamma, int accumulate_dgamma,
                          void* workspace, size_t workspace_bytes, int n, int hw, int dk, int c, void* stream);
+
+/* ---- channel / spatial attention primitives (ChannelAttention base_networks.py:366-403 and SpatialAttention :424-457 of
+ *      the discriminator, sradsgan.py:495-496; the stand-alone CLAM / SLAM of sradsgan.py:101-151), NHWC [n][hw][c],
+ *      c % 4 == 0.  The set is closed under differentiation -- pool <-> unpool (at the saved arg-max), scale <-> dot,
+ *      sigmoid_bwd -> sigmoid_bwd_bwd -- so the WGAN-GP double backward (:621, :639) is composed of these launches only.
+ * pool_hw:   t[n][2][c] = (mean, max over pixels); fixed_arg == 0 also writes arg[n][c] = first arg-max pixel,
+ *            fixed_arg != 0 reads it instead (max row = x at that pixel).   unpool_hw: out[n][p][c] = t0/hw + (p==arg)*t1.
+ * pool_c / unpool_c: the same over channels, t[n][hw][2], argc[n][hw].
+ * scale:     out = x * s; mode 0: s[n][c], mode 1: s[n][hw].   dot: mode 0: out[n][c] = sum_hw a*b, mode 1: out[n][hw] = sum_c a*b.
+ * sigmoid_*: y = sigmoid(x) (pair == 0, count elements) or y[n][c] = sigmoid(x[n][0][c] + x[n][1][c]) (pair != 0, the sum of
+ *            the two MLP branches, base_networks.py:401); bwd: dx = g y (1-y) (both rows when pair); bwd_bwd: for a
+ *            cotangent gg on dx: dg = gg y (1-y), dy = gg g (1-2y) (either output may be NULL).                   */
+int srhip_cbam_pool_hw(const float* x, float* t, int* arg, int fixed_arg, int n, int hw, int c, void* stream);
+int srhip_cbam_unpool_hw(const float* t, const int* arg, float* out, int n, int hw, int c, void* stream);
+int srhip_cbam_pool_c(const float* x, float* t, int* argc, int fixed_arg, int n, int hw, int c, void* stream);
+int srhip_cbam_unpool_c(const float* t, const int* argc, float* out, int n, int hw, int c, void* stream);
+int srhip_cbam_scale(const float* x, const float* s, float* out, int n, int hw, int c, int mode, void* stream);
+int srhip_cbam_dot(const float* a, const float* b, float* out, int n, int hw, int c, int mode, void* stream);
+int srhip_sigmoid_fwd(const float* x, float* y, long count, int c, int pair, void* stream);
+int srhip_sigmoid_bwd(const float* g, const float* y, float* dx, long count, int c, int pair, void* stream);
+int srhip_sigmoid_bwd_bwd(const float* gg, const float* g, const float* y, float* dg, float* dy, long count, int c, int pair,
+                          void* stream);
 
 /* ---- loss reductions (deterministic two-stage sums; scalars stay on the device; every fwd needs
  *      srhip_reduce_workspace() bytes of scratch; bwd kernels read the incoming scalar gradient from `gout`) --

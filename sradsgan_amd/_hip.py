@@ -52,6 +52,15 @@ SIGNATURES = {
     'srhip_sgam_flash_fwd': (_i, [_vp] * 8 + [_i] * 4 + [_vp]),
     'srhip_sgam_flash_bwd_workspace': (_sz, [_i, _i]),
     'srhip_sgam_flash_bwd': (_i, [_vp] * 11 + [_i, _vp, _sz] + [_i] * 4 + [_vp]),
+    'srhip_cbam_pool_hw': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_cbam_unpool_hw': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'srhip_cbam_pool_c': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_cbam_unpool_c': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'srhip_cbam_scale': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_cbam_dot': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_sigmoid_fwd': (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    'srhip_sigmoid_bwd': (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    'srhip_sigmoid_bwd_bwd': (_i, [_vp] * 5 + [_l, _i, _i, _vp]),
     'srhip_reduce_workspace': (_sz, []),
     'srhip_l1_mean_fwd': (_i, [_vp] * 4 + [_sz, _l, _vp]),
     'srhip_l1_mean_bwd': (_i, [_vp] * 5 + [_l, _vp]),

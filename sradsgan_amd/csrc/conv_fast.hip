@@ -335,6 +335,12 @@ __device__ inline void lds_dma16(const float* gsrc, unsigned lds_dst_uniform) {
       : "memory");
 }
 
+// LDS-DMA through a buffer descriptor: an out-of-range offset (>= num_records) makes the hardware deliver zeros, so
+// padding needs no pointer select (one 32-bit offset per lane instead of a 64-bit address and two v_cndmask).
+__device__ inline void lds_dma16_buf(unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned lds_dst_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_dst_uniform) : "memory");
+}
+
 // epilogue of one float4 of output (4 consecutive channels n.. of destination pixel dpix)
 __device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, const FastGeom& g,
                                        const float* __restrict__ bias, const float* __restrict__ residual,
@@ -708,7 +714,9 @@ __device__ __forceinline__ void patch_pixel(int r, int PH, int PW, unsigned gmap
   }
 }
 
-template <int BN, int EPI>
+// VAR: experiment bits (srhip_debug_set(3, bits << 12), only instantiated for <128, bias+lrelu>): 1 = s_setprio around the
+// MFMAs, 2 = no in-place conversion (TIMING ONLY), 4 = buffer-descriptor DMA with hardware zero fill, 8 = no stores (TIMING ONLY)
+template <int BN, int EPI, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wt,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ residual,
@@ -776,7 +784,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
   for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
 
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
+  unsigned aoffb[MAXP], boffb[BPW];                 // VAR & 4: byte offsets, out of range where the lane feeds padding
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) aoffb[k] = abase[k] >= 0 ? (unsigned)abase[k] * 4u : F_OOB;
+#pragma unroll
+  for (int j = 0; j < BPW; ++j) boffb[j] = bval[j] ? (unsigned)bbase[j] * 4u : F_OOB;
   auto issue_a = [&](int buf, int k, int cc) {      // one 1 KiB piece of the patch of chunk cc
+    if (VAR & 4) {
+      lds_dma16_buf(aoffb[k] + (unsigned)(cc * BK * 4), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
+      return;
+    }
     const float* p = abase[k] >= 0 ? src + (long)(abase[k] + cc * BK) : g_zero16;
     lds_dma16(p, a_dst + buf * PATCH_B + k * (NW * 1024));
   };
@@ -784,6 +803,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int wk = wtap[tap] + cc * BK;
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
+      if (VAR & 4) {
+        lds_dma16_buf(boffb[j] + (unsigned)(wk * 4), rs_b, b_dst + stage * BSTAGE_B + j * 1024);
+        continue;
+      }
       const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
       lds_dma16(p, b_dst + stage * BSTAGE_B + j * 1024);
     }
@@ -853,7 +876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     if (!LAST && TAP < MAXP) issue_a(pbuf ^ 1, TAP, cc + 1);
     if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
     else if (!LAST) issue_b((TAP + 2) % 3, TAP + 2 - 9, cc + 1);
-    if (!LAST && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);   // landed: it is older than B tile TAP
+    if (!(VAR & 2) && !LAST && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);   // landed: it is older than B tile TAP
     const char* pb = lds + pbuf * PATCH_B;
     const char* sb = lds + (TAP % 3) * BSTAGE_B;
     bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
@@ -867,11 +890,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boff[u]);
       bl[u] = *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16));
     }
+    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 3 * TM * TN; ++i) {          // same product order as fast_conv_dma_kernel
       const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
       acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
     }
+    if (VAR & 1) __builtin_amdgcn_s_setprio(0);
   };
   auto do_chunk = [&](auto lastc, int cc) {
     do_tap(IC<0>(), lastc, cc);
@@ -891,8 +916,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   issue_b(0, 0, 0);
   issue_b(1, 1, 0);
   wait_vmcnt<BPW>();
+  if (!(VAR & 2)) {
 #pragma unroll
-  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+    for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+  }
   for (int cc = 0; cc + 1 < CC; ++cc) do_chunk(IC<0>(), cc);
   do_chunk(IC<1>(), CC - 1);
 
@@ -921,6 +948,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int n = n0 + wn * WTN + cq * 4;
       if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
       const size_t dpix = ((size_t)img * g.Hd + oh) * g.Wd + ow;
+      if (VAR & 8) {
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+        continue;
+      }
       epi_apply_store(v, dpix, n, flags, g, bias, residual, nullptr, actmask, dst);
     }
     if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1876,6 +1907,17 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LP(BN_, 4);                 \
     SRHIP_LP(BN_, -1);                                                  \
   } while (0)
+        if (wide && eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU) && (g.flags >> 12) != 0) {   // experiment variants (sradsgan_hip.h key 3)
+          const int var = (g.flags >> 12) & 15;
+#define SRHIP_LPV(V_)                                                                                                \
+  if (var == V_) {                                                                                                   \
+    hipLaunchKernelGGL((conv_patch_kernel<128, 3, V_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias,       \
+                       residual, actmask, dst, g, pg, nbm, nbn);                                                    \
+    return check_launch("conv_patch");                                                                               \
+  }
+          SRHIP_LPV(1) SRHIP_LPV(2) SRHIP_LPV(4) SRHIP_LPV(5) SRHIP_LPV(6) SRHIP_LPV(7) SRHIP_LPV(8) SRHIP_LPV(15)
+#undef SRHIP_LPV
+        }
         if (wide) SRHIP_LPE(128);
         SRHIP_LPE(64);
 #undef SRHIP_LPE

@@ -525,13 +525,6 @@ def pixel_shuffle_act(x, r, slope=None):
 # --------------------------------------------------------------------------------------------- #
 
 
-def _clam_logits(avg, mx, fc1_w, fc2_w):
-    """[B,C] pooled vectors -> sigmoid(MLP(avg) + MLP(max)) (sradsgan.py:110-112,124-126)."""
-    hid, c = fc1_w.shape[0], fc1_w.shape[1]
-    w1, w2 = fc1_w.reshape(hid, c), fc2_w.reshape(c, hid)
-    return torch.sigmoid(torch.relu(avg @ w1.t()) @ w2.t() + torch.relu(mx @ w1.t()) @ w2.t())
-
-
 def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
     """returns (out, tensors to save for _tail_backward)."""
     n, c, h, w = u.shape
@@ -659,38 +652,230 @@ def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc):
 
 
 # --------------------------------------------------------------------------------------------- #
-# attention / normalisation glue.  TRANSITIONAL: the functions below are still compositions of
-# torch device ops (ATen HIP kernels) around the HIP convs; each is being replaced by a fused HIP
-# kernel behind the same Python signature (DESIGN.md lists what is still on ATen).
+# channel / spatial attention outside the fused RAB tail: the discriminator's ChannelAttention(256) /
+# SpatialAttention (base_networks.py:366-457, sradsgan.py:495-496) and the stand-alone CLAM / SLAM modules.
+# Built from the srhip_cbam_* primitives, whose backward passes are again primitives: every Function below is
+# differentiable as often as autograd asks (the gradient penalty differentiates the discriminator twice).
 # --------------------------------------------------------------------------------------------- #
 
 
-def _mlp_1x1(v, fc1_w, fc2_w):
-    """v: [B,C,1,1]; the two bias-free 1x1 convs of CLAM (sradsgan.py:110-112) as matmuls."""
-    b, c = v.shape[0], v.shape[1]
-    hid = torch.relu(v.reshape(b, c) @ fc1_w.reshape(fc1_w.shape[0], c).t())
-    return (hid @ fc2_w.reshape(c, fc1_w.shape[0]).t()).reshape(b, c, 1, 1)
+def _nhwc_dims(x):
+    n, c, h, w = x.shape
+    return n, h * w, c
+
+
+class _PoolHW(Function):
+    """[n,c,h,w] -> t [n,2,c] = (mean, max) over pixels; the first arg-max pixel is remembered."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, 'cbam_pool_hw')
+        x = nhwc(x)
+        n, hw, c = _nhwc_dims(x)
+        t = torch.empty(n, 2, c, device=x.device, dtype=torch.float32)
+        arg = torch.empty(n, c, device=x.device, dtype=torch.int32)
+        _hip.check(_hip.lib().srhip_cbam_pool_hw(_p(x), _p(t), _p(arg), 0, n, hw, c, _stream()), 'cbam_pool_hw')
+        ctx.arg, ctx.shape = arg, tuple(x.shape)
+        return t
+
+    @staticmethod
+    def backward(ctx, gt):
+        return _UnpoolHW.apply(gt, ctx.arg, ctx.shape)
+
+
+class _UnpoolHW(Function):
+    """t [n,2,c] -> [n,c,h,w]: t0 / hw everywhere + t1 at the remembered arg-max pixel (adjoint of the pooling)."""
+
+    @staticmethod
+    def forward(ctx, t, arg, shape):
+        t = t.contiguous()
+        n, c, h, w = shape
+        out = torch.empty(shape, device=t.device, dtype=torch.float32).contiguous(memory_format=CL)
+        _hip.check(_hip.lib().srhip_cbam_unpool_hw(_p(t), _p(arg), _p(out), n, h * w, c, _stream()), 'cbam_unpool_hw')
+        ctx.arg = arg
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RepoolHW.apply(g, ctx.arg), None, None
+
+
+class _RepoolHW(Function):
+    """pooling at a GIVEN arg-max (linear in x)."""
+
+    @staticmethod
+    def forward(ctx, x, arg):
+        x = nhwc(x)
+        n, hw, c = _nhwc_dims(x)
+        t = torch.empty(n, 2, c, device=x.device, dtype=torch.float32)
+        _hip.check(_hip.lib().srhip_cbam_pool_hw(_p(x), _p(t), _p(arg), 1, n, hw, c, _stream()), 'cbam_pool_hw')
+        ctx.arg, ctx.shape = arg, tuple(x.shape)
+        return t
+
+    @staticmethod
+    def backward(ctx, gt):
+        return _UnpoolHW.apply(gt, ctx.arg, ctx.shape), None
+
+
+class _PoolC(Function):
+    """[n,c,h,w] -> t [n,2,h,w] (NHWC memory [n][hw][2]) = (mean, max) over channels; first arg-max channel remembered."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, 'cbam_pool_c')
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        t = empty_nhwc(n, 2, h, w, x)
+        argc = torch.empty(n, h * w, device=x.device, dtype=torch.int32)
+        _hip.check(_hip.lib().srhip_cbam_pool_c(_p(x), _p(t), _p(argc), 0, n, h * w, c, _stream()), 'cbam_pool_c')
+        ctx.argc, ctx.shape = argc, tuple(x.shape)
+        return t
+
+    @staticmethod
+    def backward(ctx, gt):
+        return _UnpoolC.apply(gt, ctx.argc, ctx.shape)
+
+
+class _UnpoolC(Function):
+    @staticmethod
+    def forward(ctx, t, argc, shape):
+        t = nhwc(t)
+        n, c, h, w = shape
+        out = torch.empty(shape, device=t.device, dtype=torch.float32).contiguous(memory_format=CL)
+        _hip.check(_hip.lib().srhip_cbam_unpool_c(_p(t), _p(argc), _p(out), n, h * w, c, _stream()), 'cbam_unpool_c')
+        ctx.argc = argc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RepoolC.apply(g, ctx.argc), None, None
+
+
+class _RepoolC(Function):
+    @staticmethod
+    def forward(ctx, x, argc):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        t = empty_nhwc(n, 2, h, w, x)
+        _hip.check(_hip.lib().srhip_cbam_pool_c(_p(x), _p(t), _p(argc), 1, n, h * w, c, _stream()), 'cbam_pool_c')
+        ctx.argc, ctx.shape = argc, tuple(x.shape)
+        return t
+
+    @staticmethod
+    def backward(ctx, gt):
+        return _UnpoolC.apply(gt, ctx.argc, ctx.shape), None
+
+
+class _Scale(Function):
+    """x * s with s broadcast over pixels (mode 0, s [n,c]) or over channels (mode 1, s [n,hw]); bilinear."""
+
+    @staticmethod
+    def forward(ctx, x, s, mode):
+        _require_gpu(x, 'cbam_scale')
+        xc, sc = nhwc(x), s.contiguous()
+        n, hw, c = _nhwc_dims(xc)
+        out = torch.empty_like(xc, memory_format=CL)
+        _hip.check(_hip.lib().srhip_cbam_scale(_p(xc), _p(sc), _p(out), n, hw, c, mode, _stream()), 'cbam_scale')
+        ctx.mode = mode
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        dx = _Scale.apply(g, s, ctx.mode) if ctx.needs_input_grad[0] else None
+        ds = _Dot.apply(g, x, ctx.mode).view(s.shape) if ctx.needs_input_grad[1] else None
+        return dx, ds, None
+
+
+class _Dot(Function):
+    """sum over pixels (mode 0 -> [n,c]) or over channels (mode 1 -> [n,hw]) of a * b; bilinear."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        _require_gpu(a, 'cbam_dot')
+        ac, bc = nhwc(a), nhwc(b)
+        n, hw, c = _nhwc_dims(ac)
+        out = torch.empty((n, c) if mode == 0 else (n, hw), device=a.device, dtype=torch.float32)
+        _hip.check(_hip.lib().srhip_cbam_dot(_p(ac), _p(bc), _p(out), n, hw, c, mode, _stream()), 'cbam_dot')
+        ctx.mode = mode
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = _Scale.apply(b, g, ctx.mode) if ctx.needs_input_grad[0] else None
+        db = _Scale.apply(a, g, ctx.mode) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+class _Sigmoid(Function):
+    """pair == 0: elementwise; pair != 0: x [n,2,c] -> sigmoid(x[:,0] + x[:,1]) (the two MLP branches, base_networks.py:401)."""
+
+    @staticmethod
+    def forward(ctx, x, pair):
+        _require_gpu(x, 'sigmoid')
+        xc = x.contiguous()
+        c = xc.shape[-1] if pair else 1
+        y = torch.empty((xc.shape[0], c) if pair else tuple(xc.shape), device=x.device, dtype=torch.float32)
+        _hip.check(_hip.lib().srhip_sigmoid_fwd(_p(xc), _p(y), y.numel(), c, int(pair), _stream()), 'sigmoid_fwd')
+        ctx.pair, ctx.xshape = pair, tuple(x.shape)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _SigmoidBwd.apply(g, y, ctx.pair, ctx.xshape), None
+
+
+class _SigmoidBwd(Function):
+    @staticmethod
+    def forward(ctx, g, y, pair, xshape):
+        gc = g.contiguous()
+        dx = torch.empty(xshape, device=g.device, dtype=torch.float32)
+        _hip.check(_hip.lib().srhip_sigmoid_bwd(_p(gc), _p(y), _p(dx), y.numel(), y.shape[-1] if pair else 1, int(pair), _stream()),
+                   'sigmoid_bwd')
+        ctx.pair = pair
+        ctx.save_for_backward(g, y)
+        return dx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        g, y = ctx.saved_tensors
+        ggc, gc = gg.contiguous(), g.contiguous()
+        dg = torch.empty_like(gc) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        _hip.check(_hip.lib().srhip_sigmoid_bwd_bwd(_p(ggc), _p(gc), _p(y), _p(dg), _p(dy), y.numel(),
+                                                    y.shape[-1] if ctx.pair else 1, int(ctx.pair), _stream()), 'sigmoid_bwd_bwd')
+        return dg, dy, None, None
 
 
 def clam(x, fc1_w, fc2_w, pool_mode='Avg|Max'):
-    """sradsgan.py:117-127 / base_networks.py:387-403."""
-    logits = 0
-    if 'Avg' in pool_mode:
-        logits = logits + _mlp_1x1(x.mean((2, 3), keepdim=True), fc1_w, fc2_w)
-    if 'Max' in pool_mode:
-        logits = logits + _mlp_1x1(x.amax((2, 3), keepdim=True), fc1_w, fc2_w)
-    return torch.sigmoid(logits) * x
+    """sradsgan.py:117-127 / base_networks.py:387-403: sigmoid(MLP(avgpool x) + MLP(maxpool x)) * x; the shared
+    bias-free MLP is the reference's two 1x1 convs, applied to the stacked (avg, max) rows in one pass."""
+    if pool_mode != 'Avg|Max':
+        raise NotImplementedError("clam: only pool_mode 'Avg|Max' is built by the SRADSGAN path (sradsgan.py:669-671)")
+    n, c = x.shape[0], x.shape[1]
+    t = _PoolHW.apply(x)                                                  # [n,2,c]
+    rows = t.view(2 * n, 1, 1, c).permute(0, 3, 1, 2)                     # logical [2n,c,1,1], NHWC memory: a free view
+    hid = conv2d(rows, fc1_w, None, 1, 0, act_slope=0.0)                  # ReLU fused
+    logits = conv2d(hid, fc2_w, None, 1, 0)                               # [2n,c,1,1]
+    s = _Sigmoid.apply(logits.permute(0, 2, 3, 1).reshape(n, 2, c), True)  # [n,c]
+    return _Scale.apply(x, s, 0)
 
 
 def slam(x, w7, pool_mode='Avg|Max'):
-    """sradsgan.py:141-151 / base_networks.py:440-457: the 7x7 (2->1) conv runs on the HIP igemm."""
-    maps = []
-    if 'Avg' in pool_mode:
-        maps.append(x.mean(dim=1, keepdim=True))
-    if 'Max' in pool_mode:
-        maps.append(x.max(dim=1, keepdim=True)[0])
-    pooled = torch.cat(maps, dim=1)
-    return torch.sigmoid(conv2d(pooled, w7, None, 1, w7.shape[-1] // 2)) * x
+    """sradsgan.py:141-151 / base_networks.py:440-457: sigmoid(conv kxk([mean_c x, max_c x])) * x."""
+    if pool_mode != 'Avg|Max':
+        raise NotImplementedError("slam: only pool_mode 'Avg|Max' is built by the SRADSGAN path (sradsgan.py:669-671)")
+    n, c, h, w = x.shape
+    pooled = _PoolC.apply(x)                                              # [n,2,h,w]
+    logit = conv2d(pooled, w7, None, 1, w7.shape[-1] // 2)                # [n,1,h,w]
+    m = _Sigmoid.apply(logit.reshape(n, h * w), False)
+    return _Scale.apply(x, m, 1)
 
 
 def _ws(nbytes, like):

@@ -145,3 +145,38 @@ def test_loss_reduction_kernels_against_torch():
     assert abs(float(ph) - float(pr)) < 1e-6 * max(1.0, float(pr))
     assert _err(gh.grad, gr.grad) < 1e-5
     assert float(gh.grad[0, :, 0, 0].abs().max()) == 0.0
+
+
+def _cbam_ref(x, fc1, fc2, w7):
+    """ChannelAttention -> SpatialAttention of the discriminator (base_networks.py:387-403, 440-457) in plain torch."""
+    import torch.nn.functional as F
+    mlp = lambda v: F.conv2d(F.relu(F.conv2d(v, fc1)), fc2)
+    s = torch.sigmoid(mlp(F.adaptive_avg_pool2d(x, 1)) + mlp(F.adaptive_max_pool2d(x, 1)))
+    y = s * x
+    pooled = torch.cat([y.mean(dim=1, keepdim=True), y.max(dim=1, keepdim=True)[0]], dim=1)
+    return torch.sigmoid(F.conv2d(pooled, w7, padding=3)) * y
+
+
+@pytest.mark.parametrize('b,c,h,w', [(2, 256, 27, 27), (3, 64, 10, 12)])
+def test_discriminator_attention_pair_first_and_second_order(b, c, h, w):
+    """The srhip_cbam_* composition at the discriminator's shape (C = 256 @ 27 x 27): forward, first-order gradients and the
+    gradient-penalty pattern (a function of d out / d x differentiated again w.r.t. x and the weights) against float64."""
+    from sradsgan_amd import ops
+    x, dy, r = _rand((b, c, h, w), 41), _rand((b, c, h, w), 42), _rand((b, c, h, w), 43)
+    fc1, fc2, w7 = _rand((c // 16, c, 1, 1), 44, 0.3), _rand((c, c // 16, 1, 1), 45, 0.3), _rand((1, 2, 7, 7), 46, 0.3)
+
+    def run(dev, dtype):
+        xs, f1, f2, k7 = (t.to(dev, dtype).requires_grad_(True) for t in (x, fc1, fc2, w7))
+        if dev == 'cpu':
+            out = _cbam_ref(xs, f1, f2, k7)
+        else:
+            out = ops.slam(ops.clam(xs, f1, f2), k7)
+        (gx,) = torch.autograd.grad(out, xs, dy.to(dev, dtype), create_graph=True)
+        pen = (gx * r.to(dev, dtype)).sum() + 0.1 * (gx * gx).sum()
+        g2 = torch.autograd.grad(pen, [xs, f1, f2, k7])
+        (g1,) = torch.autograd.grad(out, xs, dy.to(dev, dtype))
+        return [out.detach(), g1, gx.detach()] + list(g2)
+    ref = run('cpu', torch.float64)
+    got = run(DEV, torch.float32)
+    for name, a_, r_ in zip(('out', 'dx', 'dx(graph)', 'pen/dx', 'pen/dfc1', 'pen/dfc2', 'pen/dw7'), got, ref):
+        assert _err(a_, r_) < 5e-4, (name, _err(a_, r_))
