@@ -43,9 +43,13 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, d
 # conv arithmetic (include/sradsgan_hip.h srhip_set_conv_math): 'bf16x3' spends three bf16 MFMA products per fp32
 # multiply-accumulate, so the ceiling for ALGORITHMIC flops is a third of the bf16 peak
 MATH_PEAK = {'fp32': (FP32_MFMA_PEAK_TFLOPS, 'f32 MFMA dense'),
-             'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 'bf16 MFMA dense 2500 TFLOP/s / 3 products per fp32 MAC')}
+             'bf16x3': (BF16_MFMA_PEAK_TFLOPS / 3.0, 'bf16 MFMA dense 2500 TFLOP/s / 3 products per fp32 MAC'),
+             'half': (BF16_MFMA_PEAK_TFLOPS, 'fp16 / bf16 MFMA dense, one product per MAC')}
 # headline `dtype`: tensors, accumulators and reductions are fp32 in both modes; the label says how the conv products are formed
-DTYPE_LABEL = {'fp32': 'f32 (exact fp32 products)', 'bf16x3': 'f32 (split-bf16 products: 3 bf16 MFMA terms per fp32 multiply, fp32 accumulate)'}
+DTYPE_LABEL = {'fp32': 'f32 (exact fp32 products)', 'bf16x3': 'f32 (split-bf16 products: 3 bf16 MFMA terms per fp32 multiply, fp32 accumulate)',
+               'half': 'f16 (one 16-bit MFMA product per multiply: fp16 on activations, bf16 on gradients; fp32 accumulate and tensors)'}
+# algorithmic GFLOP per image per training iteration at each scale of BASELINE configs[4] (HR 216 x 216)
+GF_PER_IMG_ITER_BY_SCALE = {2: 986.6, 3: 516.1, 4: 362.6, 8: 216.9, 9: 204.8}
 GF_PER_IMG_ITER = 362.6                # algorithmic GFLOP per image per training iteration (x4)
 
 
@@ -59,9 +63,10 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the compute part from a captured hipGraph (experimental, see DESIGN.md section 6)')
     ap.add_argument('--no-graph', action='store_true', help='(default) launch every kernel eagerly')
-    ap.add_argument('--conv-math', choices=('fp32', 'bf16x3'), default=None,
-                    help="arithmetic of the conv contraction: fp32 MFMA, or split-bf16 x3 MFMA with fp32 accumulate "
-                         "(default: the library default, sradsgan_amd/_hip.py DEFAULT_CONV_MATH)")
+    ap.add_argument('--conv-math', choices=('fp32', 'bf16x3', 'half'), default=None,
+                    help="arithmetic of the conv contraction: fp32 MFMA, split-bf16 x3 MFMA with fp32 accumulate, or one "
+                         "16-bit product per multiply (fp16 activations / bf16 gradients; BASELINE configs[4]) "
+                         "(default: the library default, sradsgan_amd/_hip.py DEFAULT_CONV_MATH; 'half' for --workload chain)")
     ap.add_argument('--no-fp32-line', action='store_true', help='skip the short extra run in exact-fp32 conv arithmetic')
     ap.add_argument('--cpu-iters', type=int, default=3)
     ap.add_argument('--spinup-steps', type=int, default=25,
@@ -69,8 +74,10 @@ def parse():
                          'box runs the first ~1 s of GPU work 20-30 %% slower (clocks / first touch), which a few '
                          'warm-up steps do not cover; reported in the JSON line')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--workload', choices=['train', 'infer', 'srgan', 'sragan', 'edsr'], default='train',
-                    help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]; not the headline line)")
+    ap.add_argument('--workload', choices=['train', 'infer', 'chain', 'srgan', 'sragan', 'edsr'], default='train',
+                    help="'infer': generator-only x4 inference + device metrics (BASELINE configs[1]); 'chain': the training step at "
+                         "every scale of the chain sweep x2,x3,x4,x8,x9 on HR 216x216 tiles (BASELINE configs[4]); not the headline line")
+    ap.add_argument('--scales', default='2,3,4,8,9', help='--workload chain: comma-separated scale factors')
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
     ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
@@ -156,8 +163,10 @@ def time_dominant_kernel(device, batch):
         except (OSError, ValueError):
             traffic = {}
     out = []
-    kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_kernel<128,bias+lrelu>'}[math]
-    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>'}[math]
+    kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_kernel<128,bias+lrelu>',
+          'half': 'conv_patch_kernel<128,run-time epilogue,fp16 single product>'}[math]
+    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>',
+          'half': 'wgrad_rowtap_kernel<128,64,bf16 single product>'}[math]
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
             ('wgrad', kw + ' + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
@@ -266,6 +275,66 @@ def run_inference(args, device):
                                  'conv_math': ops.get_conv_math(), 'launch': 'eager' if args.no_graph else 'hipGraph'},
                       'gflop_per_image': 69.19, 'tflops': round(B * args.steps / dt * 69.19 / 1e3, 2),
                       'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
+
+
+def run_chain(args, device):
+    """BASELINE configs[4] on one GPU: the full training step at every scale of the chain sweep (HR tile 216 x 216, LR tile
+    216 / s, per-GPU batch as given), default arithmetic 'half'.  One JSON line: per-scale img/s and ms/step, `value` = images
+    per second over the whole sweep (the same number of steps at every scale)."""
+    import torch
+    from sradsgan_amd import model as M, ops
+    from sradsgan_amd.train_step import TrainStep
+    from sradsgan_amd.trainer import weights_init_normal
+    if not args.conv_math:
+        ops.set_conv_math('half')
+    B = args.batch
+    scales = [int(v) for v in args.scales.split(',')]
+    per, tot_t, tot_img = {}, 0.0, 0
+    for i, sc in enumerate(scales):
+        torch.manual_seed(20240 + sc)
+        G = M.GeneratorResNet(M.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=sc)
+        D, Fx = M.Discriminator(), M.FeatureExtractor()
+        G.apply(weights_init_normal), D.apply(weights_init_normal)
+        with torch.no_grad():
+            G.GAB_UP.ca.gamma.fill_(0.5), G.GAB_UP.sa.gamma.fill_(0.5)        # global attention live, as in the parity tests
+            for m in Fx.modules():                                            # VGG stand-in: He-scaled random weights
+                if 'Conv2d' in m.__class__.__name__:
+                    m.weight.normal_(0.0, (2.0 / (m.weight.shape[1] * 9)) ** 0.5)
+                    m.bias.zero_()
+        for m in (G, D, Fx):
+            m.to(device)
+        step = TrainStep(G, D, Fx)
+        gen = torch.Generator().manual_seed(1234 + sc)
+        side = 216 // sc
+        hr = torch.rand(B, 3, side * sc, side * sc, generator=gen).to(device)
+        lr = torch.rand(B, 3, side, side, generator=gen).to(device)
+        alpha = torch.rand(B, 1, 1, 1, generator=gen).to(device)
+        for _ in range((max(0, args.spinup_steps) if i == 0 else 0) + args.warmup):
+            out = step(lr, hr, alpha)
+        torch.cuda.synchronize()
+        peak0 = torch.cuda.max_memory_allocated()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(lr, hr, alpha)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        finite = all(float(out[k]) == float(out[k]) for k in ('loss_G', 'loss_D'))
+        gf = GF_PER_IMG_ITER_BY_SCALE.get(sc)
+        per['x%d' % sc] = {'img_per_s': round(B * args.steps / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 2), 'lr_side': side,
+                           'step_tflops': round(B * args.steps / dt * gf / 1e3, 1) if gf else None, 'losses_finite': finite,
+                           'peak_mem_gb': round(peak0 / 2 ** 30, 1)}
+        tot_t, tot_img = tot_t + dt, tot_img + B * args.steps
+        del step, G, D, Fx, hr, lr
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+    math = ops.get_conv_math()
+    print(json.dumps({'metric': 'chain-training images/sec over the scale sweep (HR 216x216 tiles)', 'value': round(tot_img / tot_t, 2),
+                      'unit': 'img/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': round(tot_t / (args.steps * len(scales)) * 1e3, 2), 'higher_is_better': True,
+                      'dtype': DTYPE_LABEL[math], 'data': 'synthetic',
+                      'config': {'workload': 'SRADSGAN full GAN training step at scales %s, HR 216x216, per-GPU batch %d' % (scales, B),
+                                 'conv_math': math, 'launch': 'eager'},
+                      'per_scale': per}), flush=True)
 
 
 def run_sibling(args, device):
@@ -437,6 +506,9 @@ def main():
         return
     if args.workload == 'infer':
         run_inference(args, device)
+        return
+    if args.workload == 'chain':
+        run_chain(args, device)
         return
     if args.workload in ('srgan', 'sragan', 'edsr'):
         run_sibling(args, device)

@@ -35,6 +35,7 @@ extern "C" {
 #define SRHIP_EPI_ROWSCALE 8  /* y = rowscale[pixel] * (W.x) (+bias...) : SLAM mask folded */
 #define SRHIP_EPI_ACTMASK 32  /* (dgrad) y = actmask > 0 ? y : slope*y : backward of the producer's LeakyReLU */
 #define SRHIP_EPI_CHANSCALE 16 /* x[n,h,w,c] is read as x*chanscale[n][c] : CLAM scale folded (Cin%16==0) */
+#define SRHIP_EPI_GRADDATA 64 /* (fwd) x holds gradients (second-order passes): SRHIP_MATH_HALF then multiplies in bf16, not fp16 */
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
@@ -63,14 +64,21 @@ int srhip_debug_set(int key, int value);
  * always compute in fp32.                                                                        */
 #define SRHIP_MATH_FP32 0
 #define SRHIP_MATH_BF16X3 1
+/*   SRHIP_MATH_HALF    one 16-bit product per multiply, fp32 accumulate, fp32 tensors (BASELINE configs[4]: "fp16 MFMA"):
+ *                      forward convolutions of activations round both operands to fp16 (v_mfma_f32_32x32x16_f16, ~2^-11
+ *                      per operand); everything that multiplies GRADIENTS (dgrad, wgrad, forward calls flagged
+ *                      SRHIP_EPI_GRADDATA) rounds to bf16 instead (v_mfma_f32_32x32x16_bf16): gradients of a mean-reduced
+ *                      loss sit far below fp16's range and bf16 needs no loss scaling.  Does NOT meet the 1e-3 parity
+ *                      contract of configs[1..3]; judged on PSNR (<= 0.05 dB) and loss drift instead.       */
+#define SRHIP_MATH_HALF 2
 int srhip_set_conv_math(int mode);
 int srhip_get_conv_math(void);
 
 /* ---- weight packing ------------------------------------------------------------------------ *
  * OIHW parameter -> the GEMM "B" operand the conv kernels read.  mode 0 = fprop operand,
  * mode 1 = dgrad operand.  The internal layout depends only on (cout,cin,kh,kw,mode); the buffer
- * must hold srhip_packed_elems() floats (for Cin % 16 == 0 shapes: an fp32 copy plus a pre-split
- * bf16 hi/lo copy for SRHIP_MATH_BF16X3).  Runs once per optimiser step per conv.                */
+ * must hold srhip_packed_elems() floats (for Cin % 16 == 0 shapes: an fp32 copy, a pre-split
+ * bf16 hi/lo copy for SRHIP_MATH_BF16X3 and an fp16 copy for SRHIP_MATH_HALF).  Runs once per optimiser step per conv. */
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode);
 int srhip_pack_weight(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw, int mode,
                       void* stream);

@@ -111,9 +111,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         mode = os.environ.get('SRADSGAN_CONV_MATH', DEFAULT_CONV_MATH)
-        if mode not in ('fp32', 'bf16x3'):
-            raise HipLibraryError("SRADSGAN_CONV_MATH must be 'fp32' or 'bf16x3', got %r" % mode)
-        handle.srhip_set_conv_math(1 if mode == 'bf16x3' else 0)
+        if mode not in ('fp32', 'bf16x3', 'half'):
+            raise HipLibraryError("SRADSGAN_CONV_MATH must be 'fp32', 'bf16x3' or 'half', got %r" % mode)
+        handle.srhip_set_conv_math({'fp32': 0, 'bf16x3': 1, 'half': 2}[mode])
         for item in os.environ.get('SRHIP_DEBUG', '').split(','):      # experiment knobs, "key:value,..." (sradsgan_hip.h)
             if item:
                 key, value = item.split(':')

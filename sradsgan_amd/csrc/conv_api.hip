@@ -84,7 +84,7 @@ int srhip_debug_set(int key, int value) {
 }
 
 int srhip_set_conv_math(int mode) {
-  SRHIP_REQUIRE(mode == SRHIP_MATH_FP32 || mode == SRHIP_MATH_BF16X3, "set_conv_math: unknown mode");
+  SRHIP_REQUIRE(mode == SRHIP_MATH_FP32 || mode == SRHIP_MATH_BF16X3 || mode == SRHIP_MATH_HALF, "set_conv_math: unknown mode");
   g_conv_math = mode;
   return SRHIP_OK;
 }
@@ -93,7 +93,7 @@ int srhip_get_conv_math(void) { return g_conv_math; }
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode) {
   if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return 0;
   const bool fast = mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw);
-  if (fast) return 2 * (size_t)cout * cin * kh * kw;   // fp32 section + split-bf16 section (fast_pack_store)
+  if (fast) return 3 * (size_t)cout * cin * kh * kw;   // fp32 + split-bf16 + fp16 sections (fast_pack_store)
   const int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
   return (size_t)kh * kw * csrc * legacy_packed_ld(cdst);
 }

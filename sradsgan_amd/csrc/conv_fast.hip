@@ -71,7 +71,37 @@ __device__ inline void split_bf16x8(const float4& v0, const float4& v1, bf16x8_t
   }
 }
 
-// MATH 1 (BK 16 only): split-bf16 products, B read from the pre-split section of the packed weights
+// 16-bit operand arithmetic of the bf16-layout kernels ("PROD"): 0 = split-bf16, three bf16 products per multiply
+// (SRHIP_MATH_BF16X3); 1 = one bf16 product, 2 = one fp16 product (SRHIP_MATH_HALF on gradient resp. activation data).
+// Fragments travel as 16-byte bags typed bf16x8_t; PROD 2 reinterprets them as 8 halves.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int PROD>
+__device__ __forceinline__ f32x16 mma16(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
+  if constexpr (PROD == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int PROD>
+__device__ __forceinline__ bf16x8_t round16x8(const float4& v0, const float4& v1) {
+  const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  if constexpr (PROD == 2) {
+    f16x8_t h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    return __builtin_bit_cast(bf16x8_t, h);
+  } else {
+    bf16x8_t h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
+    return h;
+  }
+}
+// products of one (A tile t, B tile u) pair: PROD 0: al*bh, ah*bl, ah*bh interleaved over the tiles by the caller
+template <int PROD>
+constexpr int nprod() { return PROD == 0 ? 3 : 1; }
+
+// MATH >= 1 (BK 16 only): 16-bit products (PROD = MATH - 1), B read from the pre-split / fp16 section of the packed weights
 template <int BM, int BN, int WM, int WN, int BK, int MATH = 0>
 __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __restrict__ src,
                                                                  const float* __restrict__ wt,
@@ -217,22 +247,26 @@ __global__ __launch_bounds__(WM* WN * 64) void fast_conv_kernel(const float* __r
     for (int kc = 0; kc < nk; ++kc) {
       const int stage = abl_noload ? 0 : (kc & 1);
       if (kc + 1 < nk && !abl_noload) load_tiles();
-      if (MATH == 1) {
+      if (MATH >= 1) {
+        constexpr int PROD = MATH >= 1 ? MATH - 1 : 0;
         const float* a = lds + stage * STAGE + (wm * WTM + l31) * LS + khalf * 8;
         const float* b = lds + stage * STAGE + BM * LS + (wn * WTN + l31) * LS + khalf * 8;
         bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
-          split_bf16x8(*reinterpret_cast<const float4*>(a + t * 32 * LS), *reinterpret_cast<const float4*>(a + t * 32 * LS + 4), ah[t], al[t]);
+        for (int t = 0; t < TM; ++t) {
+          const float4 a0 = *reinterpret_cast<const float4*>(a + t * 32 * LS), a1 = *reinterpret_cast<const float4*>(a + t * 32 * LS + 4);
+          if (PROD == 0) split_bf16x8(a0, a1, ah[t], al[t]);
+          else ah[t] = al[t] = round16x8<PROD>(a0, a1);
+        }
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
           bh[u] = *reinterpret_cast<const bf16x8_t*>(b + u * 32 * LS);
-          bl[u] = *reinterpret_cast<const bf16x8_t*>(b + u * 32 * LS + 4);
+          bl[u] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(b + u * 32 * LS + 4) : bh[u];
         }
 #pragma unroll
-        for (int i = 0; i < 3 * TM * TN; ++i) {
-          const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+        for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {
+          const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
+          acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
         }
         if (kc + 1 < nk && !abl_noload) store_tiles(stage ^ 1);
         if (!abl_nobar) __syncthreads();
@@ -456,21 +490,19 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
   const int CC = g.C / BK;
   const int nk = g.TH * g.TW * CC;
   int th = 0, tw = 0, cc = 0;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
   auto issue = [&](int stage) {
     const int tapoff = ((g.dh0 + th * g.dhs) * g.Ws + (g.dw0 + tw * g.dws)) * g.lds + cc * BK;
     const int wk = ((g.kh0 + th * g.khs) * g.KW + (g.kw0 + tw * g.kws)) * g.C + cc * BK;
     const int bit = th * g.TW + tw;
     const unsigned so = stage * STAGE_B;
+    // buffer-descriptor DMA: a lane that feeds padding carries an out-of-range offset and the hardware writes zeros
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const float* p = ((amask[i] >> bit) & 1u) ? src + (long)(abase[i] + tapoff) : g_zero16;
-      lds_dma16(p, a_dst + so + i * 1024);
-    }
+    for (int i = 0; i < AI; ++i)
+      lds_dma16_buf(((amask[i] >> bit) & 1u) ? (unsigned)(abase[i] + tapoff) * 4u : F_OOB, rs_a, a_dst + so + i * 1024);
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-      const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
-      lds_dma16(p, b_dst + so + j * 1024);
-    }
+    for (int j = 0; j < BI; ++j) lds_dma16_buf(bval[j] ? (unsigned)(bbase[j] + wk) * 4u : F_OOB, rs_b, b_dst + so + j * 1024);
     // taps innermost: the 9 taps of one 16-channel chunk re-read the same 64-byte segments of ~3 image
     // rows back to back (L1/L2 hits); with taps outermost a 256-channel input was re-fetched 9x from
     // beyond L2 (FETCH_SIZE 788 MB vs 96 MB algorithmic, profiles/r01_conv_pmc_summary.txt)
@@ -588,7 +620,8 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
       nstage = nstage == 2 ? 0 : nstage + 1;
     }
   }
-  if (MATH == 1 && nk > 0) {
+  if (MATH >= 1 && nk > 0) {
+    constexpr int PROD = MATH >= 1 ? MATH - 1 : 0;
     // split-bf16: A fragments are split in registers, B was split when it was packed.  (Interleaving the split of
     // chunk kc+1 with the MFMAs of chunk kc by hand measured the same: the loop is bound by LDS-DMA issue and the
     // per-chunk barrier, not by VALU/MFMA overlap -- DESIGN.md.)
@@ -602,16 +635,19 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
       read_frags(stage, af, bf);
       bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) split_bf16x8(af[0][t], af[1][t], ah[t], al[t]);
-#pragma unroll
-      for (int u = 0; u < TN; ++u) {   // weights were split when they were packed (fast_pack_store)
-        bh[u] = __builtin_bit_cast(bf16x8_t, bf[0][u]);
-        bl[u] = __builtin_bit_cast(bf16x8_t, bf[1][u]);
+      for (int t = 0; t < TM; ++t) {
+        if (PROD == 0) split_bf16x8(af[0][t], af[1][t], ah[t], al[t]);
+        else ah[t] = al[t] = round16x8<PROD>(af[0][t], af[1][t]);
       }
 #pragma unroll
-      for (int i = 0; i < 3 * TM * TN; ++i) {          // product order al*bh, ah*bl, ah*bh; accumulator chains interleaved
-        const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+      for (int u = 0; u < TN; ++u) {   // weights were split / rounded when they were packed (fast_pack_store)
+        bh[u] = __builtin_bit_cast(bf16x8_t, bf[0][u]);
+        bl[u] = PROD == 0 ? __builtin_bit_cast(bf16x8_t, bf[1][u]) : bh[u];
+      }
+#pragma unroll
+      for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {   // product order al*bh, ah*bl, ah*bh; accumulator chains interleaved
+        const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
+        acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
       }
       stage = stage == 2 ? 0 : stage + 1;
       nstage = nstage == 2 ? 0 : nstage + 1;
@@ -714,9 +750,7 @@ __device__ __forceinline__ void patch_pixel(int r, int PH, int PW, unsigned gmap
   }
 }
 
-// VAR: experiment bits (srhip_debug_set(3, bits << 12), only instantiated for <128, bias+lrelu>): 1 = s_setprio around the
-// MFMAs, 2 = no in-place conversion (TIMING ONLY), 4 = buffer-descriptor DMA with hardware zero fill, 8 = no stores (TIMING ONLY)
-template <int BN, int EPI, int VAR = 0>
+template <int BN, int EPI, int PROD = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_kernel(const float* __restrict__ src, const float* __restrict__ wt,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ residual,
@@ -784,32 +818,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
   for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
 
+  // DMA through buffer descriptors: lanes that feed padding (outside the image / past the last destination channel)
+  // carry an out-of-range offset and the hardware delivers zeros -- one 32-bit add per DMA instead of a 64-bit
+  // address and a pointer select (measured -2.5 % on the 64 -> 256 fprop, bit-identical)
   __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
-  unsigned aoffb[MAXP], boffb[BPW];                 // VAR & 4: byte offsets, out of range where the lane feeds padding
+  unsigned aoffb[MAXP], boffb[BPW];
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) aoffb[k] = abase[k] >= 0 ? (unsigned)abase[k] * 4u : F_OOB;
 #pragma unroll
   for (int j = 0; j < BPW; ++j) boffb[j] = bval[j] ? (unsigned)bbase[j] * 4u : F_OOB;
   auto issue_a = [&](int buf, int k, int cc) {      // one 1 KiB piece of the patch of chunk cc
-    if (VAR & 4) {
-      lds_dma16_buf(aoffb[k] + (unsigned)(cc * BK * 4), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
-      return;
-    }
-    const float* p = abase[k] >= 0 ? src + (long)(abase[k] + cc * BK) : g_zero16;
-    lds_dma16(p, a_dst + buf * PATCH_B + k * (NW * 1024));
+    lds_dma16_buf(aoffb[k] + (unsigned)(cc * BK * 4), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
   };
   auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
     const int wk = wtap[tap] + cc * BK;
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) {
-      if (VAR & 4) {
-        lds_dma16_buf(boffb[j] + (unsigned)(wk * 4), rs_b, b_dst + stage * BSTAGE_B + j * 1024);
-        continue;
-      }
-      const float* p = bval[j] ? wt + (long)(bbase[j] + wk) : g_zero16;
-      lds_dma16(p, b_dst + stage * BSTAGE_B + j * 1024);
-    }
+    for (int j = 0; j < BPW; ++j) lds_dma16_buf(boffb[j] + (unsigned)(wk * 4), rs_b, b_dst + stage * BSTAGE_B + j * 1024);
   };
   // fp32 -> split bf16 in place for one piece this wave fetched: lanes 2i, 2i+1 hold the two quads (8 consecutive
   // channels) of a half row; the lane with the even quad keeps the 8 hi halves, the odd one the 8 lo halves
@@ -823,8 +848,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
     const bool odd = aq & 1;                        // this lane's quad is the second half of the 8-group
     bf16x8_t hi, lo;
-    split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
-    *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
+    if (PROD == 0) {
+      split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
+      *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
+    } else if (!odd) {                              // single product: the even lane's slot takes the 8 rounded values
+      *reinterpret_cast<bf16x8_t*>(slot) = round16x8<PROD>(own, oth);
+    }
   };
 
   // ---- fragment addressing: everything but the patch-buffer parity is fixed for the whole kernel ----
@@ -876,27 +905,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     if (!LAST && TAP < MAXP) issue_a(pbuf ^ 1, TAP, cc + 1);
     if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
     else if (!LAST) issue_b((TAP + 2) % 3, TAP + 2 - 9, cc + 1);
-    if (!(VAR & 2) && !LAST && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);   // landed: it is older than B tile TAP
+    if (!LAST && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);   // landed: it is older than B tile TAP
     const char* pb = lds + pbuf * PATCH_B;
     const char* sb = lds + (TAP % 3) * BSTAGE_B;
     bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       ah[t] = *reinterpret_cast<const bf16x8_t*>(pb + aoff[TAP][t]);
-      al[t] = *reinterpret_cast<const bf16x8_t*>(pb + (aoff[TAP][t] ^ 16));
+      al[t] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(pb + (aoff[TAP][t] ^ 16)) : ah[t];
     }
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
       bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boff[u]);
-      bl[u] = *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16));
+      bl[u] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16)) : bh[u];
     }
-    if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 3 * TM * TN; ++i) {          // same product order as fast_conv_dma_kernel
-      const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
-      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
+    for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {   // same product order as fast_conv_dma_kernel
+      const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
+      acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
     }
-    if (VAR & 1) __builtin_amdgcn_s_setprio(0);
   };
   auto do_chunk = [&](auto lastc, int cc) {
     do_tap(IC<0>(), lastc, cc);
@@ -916,10 +943,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   issue_b(0, 0, 0);
   issue_b(1, 1, 0);
   wait_vmcnt<BPW>();
-  if (!(VAR & 2)) {
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
-  }
+  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
   for (int cc = 0; cc + 1 < CC; ++cc) do_chunk(IC<0>(), cc);
   do_chunk(IC<1>(), CC - 1);
 
@@ -948,10 +973,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int n = n0 + wn * WTN + cq * 4;
       if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
       const size_t dpix = ((size_t)img * g.Hd + oh) * g.Wd + ow;
-      if (VAR & 8) {
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-        continue;
-      }
       epi_apply_store(v, dpix, n, flags, g, bias, residual, nullptr, actmask, dst);
     }
     if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1416,6 +1437,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
         // pixel rows khalf*8 .. khalf*8+7 of each 16-pixel step (a/b above start at row khalf: rebase to khalf*8)
         const float* a8 = a + 7 * khalf * BM;
         const float* b8 = b + 7 * khalf * BN;
+        constexpr bool SPLIT = MATH == 1;               // MATH 2: one bf16 product (SRHIP_MATH_HALF)
 #pragma unroll
         for (int ks = 0; ks < WBK / 16; ++ks) {
           bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
@@ -1424,23 +1446,27 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = a8[(ks * 16 + j) * BM + t * 32];
-            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ah[t], al[t]);
+            if (SPLIT) split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ah[t], al[t]);
+            else ah[t] = al[t] = round16x8<1>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
           }
 #pragma unroll
           for (int u = 0; u < TN; ++u) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = b8[(ks * 16 + j) * BN + u * 32];
-            split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bh[u], bl[u]);
+            if (SPLIT) split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), bh[u], bl[u]);
+            else bh[u] = bl[u] = round16x8<1>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
           }
+          if (SPLIT) {
 #pragma unroll
-          for (int t = 0; t < TM; ++t)
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
+              for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TM; ++t)
+            for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+              for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+          }
 #pragma unroll
           for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -1497,7 +1523,7 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
 // LDS: 3-slot ring of [16 px][BM] dy + [20 px][64] x (fp32, lane-linear LDS-DMA images); same split-K partial
 // layout, reduce kernel and XCD mapping as the other wgrad kernels.
 // ================================================================================================ //
-template <int BM, int CIS>
+template <int BM, int CIS, bool SPLIT = true>     // SPLIT false: one bf16 product per multiply (SRHIP_MATH_HALF)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_rowtap_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
     float* __restrict__ bias_partial, WgradGeom g, int nseg, int chunks_per_split) {
@@ -1556,6 +1582,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * NA * 1024);
   const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + A_B + b_first * 1024);
 
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, g.dy_bytes, 0x00020000);
   int i_n, i_ho, i_seg;                             // chunk the next issue() fetches (scalars)
   {
     i_seg = c_begin % nseg;
@@ -1569,8 +1597,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int j = (wave * NA + i) * RPA + a_rsub;            // output pixel slot 0..15
-      const float* ptr = (a_colok && wo0 + j < g.Wo) ? dy + ((prow + j) * g.ldy + m0 + a_col * 4) : g_zero16;
-      lds_dma16(ptr, a_dst + slot * STAGE_B + i * 1024);
+      const unsigned off = (a_colok && wo0 + j < g.Wo) ? (unsigned)((prow + j) * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
+      lds_dma16_buf(off, rs_y, a_dst + slot * STAGE_B + i * 1024);   // out of range => the hardware writes zeros
     }
     const int hi = i_ho - 1 + kh;
     const bool rowok = hi >= 0 && hi < g.H;
@@ -1581,8 +1609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
         const int r = (b_first + i) * RPB + b_rsub;            // staged pixel row: input column wo0 - 1 + r
         const int wi = wo0 - 1 + r;
         const bool ok = rowok && r < 18 && wi >= 0 && wi < g.W;
-        const float* ptr = ok ? x + ((xrow + wi) * g.ldx + ci_base + b_col * 4) : g_zero16;
-        lds_dma16(ptr, b_dst + slot * STAGE_B + i * 1024);
+        lds_dma16_buf(ok ? (unsigned)((xrow + wi) * g.ldx + ci_base + b_col * 4) * 4u : F_OOB, rs_x, b_dst + slot * STAGE_B + i * 1024);
       }
     }
     if (++i_seg == nseg) {
@@ -1663,8 +1690,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
         bh[2] = __builtin_bit_cast(bf16x8_t, h2); bl[2] = __builtin_bit_cast(bf16x8_t, l2);
       }
 #pragma unroll
-      for (int i = 0; i < 3 * TM * TN; ++i) {
-        const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+      for (int i = 0; i < (SPLIT ? 3 : 1) * TM * TN; ++i) {
+        const int grp = SPLIT ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
       }
       if (want_bias) {
@@ -1704,34 +1731,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
 }
 
 // partial[s][co][(tap,ci)] --sum over s--> dw[co][ci][kh][kw];  bias_partial[s][co] --> db[co]
-__global__ __launch_bounds__(256) void fast_wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                                 const float* __restrict__ bias_partial,
-                                                                 float* __restrict__ dw, float* __restrict__ db,
-                                                                 int nsplit, int cout, int cin, int khkw, int ktot,
-                                                                 int accumulate) {
-  // 64 outputs per block x 4 split lanes; each lane keeps 4 loads in flight, LDS combines the lanes
-  __shared__ float red[256];
+// 64 outputs per block x SUB split lanes; each lane keeps 4 loads in flight, LDS combines the lanes in a fixed order.
+// SUB = 16 for the one- and two-tile GEMMs (1x1 and 64 -> 64 convs: up to 768 splits of a 16 KB tile, only 65 blocks):
+// with 4 lanes a thread walked 192 dependent-latency loads (30 us per call, 100 calls per step).
+template <int SUB>
+__global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                     const float* __restrict__ bias_partial,
+                                                                     float* __restrict__ dw, float* __restrict__ db,
+                                                                     int nsplit, int cout, int cin, int khkw, int ktot,
+                                                                     int accumulate) {
+  __shared__ float red[64 * SUB];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
   const int total = cout * ktot;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < total) {
     int i = sub;
-    for (; i + 12 < nsplit; i += 16) {
-      s0 += partial[(size_t)(i + 0) * total + e];
-      s1 += partial[(size_t)(i + 4) * total + e];
-      s2 += partial[(size_t)(i + 8) * total + e];
-      s3 += partial[(size_t)(i + 12) * total + e];
+    for (; i + 3 * SUB < nsplit; i += 4 * SUB) {
+      s0 += partial[(size_t)(i + 0 * SUB) * total + e];
+      s1 += partial[(size_t)(i + 1 * SUB) * total + e];
+      s2 += partial[(size_t)(i + 2 * SUB) * total + e];
+      s3 += partial[(size_t)(i + 3 * SUB) * total + e];
     }
-    for (; i < nsplit; i += 4) s0 += partial[(size_t)i * total + e];
+    for (; i < nsplit; i += SUB) s0 += partial[(size_t)i * total + e];
   } else if (db != nullptr && e < total + cout) {
     const int co = e - total;
-    for (int i = sub; i < nsplit; i += 4) s0 += bias_partial[(size_t)i * cout + co];
+    for (int i = sub; i < nsplit; i += SUB) s0 += bias_partial[(size_t)i * cout + co];
   }
   red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sub == 0) {
     const int t = threadIdx.x;
-    const float v = (red[t] + red[t + 64]) + (red[t + 128] + red[t + 192]);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < SUB; j += 4) v += (red[t + 64 * j] + red[t + 64 * (j + 1)]) + (red[t + 64 * (j + 2)] + red[t + 64 * (j + 3)]);
     if (e < total) {
       const int co = e / ktot, kcol = e - co * ktot;
       const int tap = kcol / cin, ci = kcol - tap * cin;
@@ -1779,7 +1811,7 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
   return check_launch("fast_pack_weight");
 }
 
-int g_conv_math = 0;     // 0: exact fp32 MFMA; 1: split-bf16 x3 MFMA (srhip_debug_set(4, mode))
+int g_conv_math = 0;     // SRHIP_MATH_*: 0 exact fp32 MFMA; 1 split-bf16 x3 MFMA; 2 one 16-bit product (fp16 activations / bf16 gradients)
 int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_fast(const float* src, const float* wt, const float* bias, const float* residual,
@@ -1862,7 +1894,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   // <= 4 destination channels, stride-1 3x3, big image: exact-fp32 VALU kernel (both arithmetic modes; cfg 22 turns it off)
   if (g.K <= 4 && g_fast_cfg != 20 && g_fast_cfg != 22 && g.TH == 3 && g.TW == 3 && g.ss == 1 && g.dsd == 1 && g.ph == 0 &&
       g.pw == 0 && g.Hd == g.OH && g.Wd == g.OW && (g.dhs == 1 || g.dhs == -1) && (g.dws == 1 || g.dws == -1) &&
-      !(g.flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) && !g.accumulate && g.M >= 65536) {
+      !(g.flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU | SRHIP_EPI_GRADDATA)) && !g.accumulate && g.M >= 65536) {
     const int th = cdiv(g.OH, 16), tw = cdiv(g.OW, 16);
     const int lo_h = g.dhs > 0 ? g.dh0 : g.dh0 + 2 * g.dhs, lo_w = g.dws > 0 ? g.dw0 : g.dw0 + 2 * g.dws;
     if (g.K == 3)
@@ -1871,19 +1903,30 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       hipLaunchKernelGGL((narrow_conv_kernel<4>), dim3(g.N * th * tw), dim3(256), 0, st, src, wt, bias, dst, g, th, tw, lo_h, lo_w);
     return check_launch("narrow_conv");
   }
-  if (g.K <= 32 && g_conv_math == 1 && g_fast_cfg != 20 && !(g.flags & (SRHIP_EPI_CHANSCALE | 0x300))) {
+  // 16-bit product arithmetic (see mma16): 0 split-bf16 (three products), 1 one bf16 product (SRHIP_MATH_HALF on gradient
+  // data: every dgrad, and forward calls flagged GRADDATA), 2 one fp16 product (SRHIP_MATH_HALF on activations)
+  const int prod = g_conv_math == 2 ? ((g.flags & SRHIP_EPI_GRADDATA) ? 1 : 2) : 0;
+  const float* w16 = wt + (size_t)(g.w_bytes >> 2) * (prod == 2 ? 2 : 1);      // packed-weight section (fast_pack_store)
+  if (g.K <= 32 && g_conv_math >= 1 && g_fast_cfg != 20 && !(g.flags & (SRHIP_EPI_CHANSCALE | 0x300))) {
     const int nbm = cdiv(g.M, 128), nbn = cdiv(g.K, 32);
-    hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,
-                       wt + (g.w_bytes >> 2), bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
+    if (prod == 0)
+      hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,
+                         w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
+    else if (prod == 1)
+      hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 2>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,
+                         w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
+    else
+      hipLaunchKernelGGL((fast_conv_kernel<128, 32, 4, 1, 16, 3>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, src,
+                         w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);
     return check_launch("fast_conv");
   }
   if (g.K <= 32) SRHIP_LF(128, 32, 4, 1, 16);
   // LDS-DMA kernels (g_fast_cfg 20 forces them off): no A-operand scaling, ablation flags or accumulate variants needed
-  const int eflags = g.flags & 0xff;      // bits 0x100/0x200: ablations (reg kernel), 0x400: plain instead of non-temporal epilogue stores
+  const int eflags = g.flags & 0x3f;      // bit 0x40: GRADDATA; 0x100/0x200: ablations (reg kernel), 0x400: plain instead of non-temporal epilogue stores
   const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   // stride-1 3x3 in split-bf16: the patch kernel (g_fast_cfg 21 turns it off, -2 forces it at any size)
-  if (g_conv_math == 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+  if (g_conv_math >= 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       !(eflags & (SRHIP_EPI_CHANSCALE | SRHIP_EPI_ROWSCALE)) && !g.accumulate) {
     PatchGeom pg;
     if (plan_patch(g, &pg)) {
@@ -1891,7 +1934,20 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       const bool wide = g.K >= 128;
       const int nbn = cdiv(g.K, wide ? 128 : 64);
       if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
-        const float* wsplit = wt + (g.w_bytes >> 2);
+        const float* wsplit = w16;
+        if (prod != 0) {                                  // SRHIP_MATH_HALF: run-time epilogue flags keep the variant count down
+#define SRHIP_LPH(BN_, PROD_)                                                                                       \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((conv_patch_kernel<BN_, -1, PROD_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias,   \
+                       residual, actmask, dst, g, pg, nbm, nbn);                                                   \
+    return check_launch("conv_patch");                                                                              \
+  } while (0)
+          if (wide && prod == 1) SRHIP_LPH(128, 1);
+          if (wide) SRHIP_LPH(128, 2);
+          if (prod == 1) SRHIP_LPH(64, 1);
+          SRHIP_LPH(64, 2);
+#undef SRHIP_LPH
+        }
 #define SRHIP_LP(BN_, EPI_)                                                                                         \
   do {                                                                                                              \
     hipLaunchKernelGGL((conv_patch_kernel<BN_, EPI_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias,       \
@@ -1907,17 +1963,6 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LP(BN_, 4);                 \
     SRHIP_LP(BN_, -1);                                                  \
   } while (0)
-        if (wide && eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU) && (g.flags >> 12) != 0) {   // experiment variants (sradsgan_hip.h key 3)
-          const int var = (g.flags >> 12) & 15;
-#define SRHIP_LPV(V_)                                                                                                \
-  if (var == V_) {                                                                                                   \
-    hipLaunchKernelGGL((conv_patch_kernel<128, 3, V_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias,       \
-                       residual, actmask, dst, g, pg, nbm, nbn);                                                    \
-    return check_launch("conv_patch");                                                                               \
-  }
-          SRHIP_LPV(1) SRHIP_LPV(2) SRHIP_LPV(4) SRHIP_LPV(5) SRHIP_LPV(6) SRHIP_LPV(7) SRHIP_LPV(8) SRHIP_LPV(15)
-#undef SRHIP_LPV
-        }
         if (wide) SRHIP_LPE(128);
         SRHIP_LPE(64);
 #undef SRHIP_LPE
@@ -1931,7 +1976,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     const bool force = g_fast_cfg == -1;                 // tests: take the DMA kernels at any problem size
     // fp32: the register-staged kernel wins below ~2 tiles per CU; split-bf16: its fp32 MFMAs cost 5x more than
     // the DMA kernel's, so the DMA kernel is taken from half a wave of tiles on
-    const long min_tiles = g_conv_math == 1 ? 128 : 512;
+    const long min_tiles = g_conv_math >= 1 ? 128 : 512;
     const bool wide = g.K >= 128 && ((long)nbm * cdiv(g.K, 128) >= min_tiles || force);
     const long b64 = (long)nbm * cdiv(g.K, 64);
     if (wide || b64 >= min_tiles || force) {
@@ -1940,7 +1985,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     const int nbn = cdiv(g.K, BN_);                                                                                \
     if (g_conv_math == 1) {                                                                                        \
       hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
-                         src, wt + (g.w_bytes >> 2), bias, residual, rowscale, chanscale, actmask, dst, g, nbm,    \
+                         src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm,                      \
                          nbn);                                                                                     \
     } else                                                                                                         \
       hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 0>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
@@ -1958,6 +2003,20 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     if (eflags == 29) SRHIP_LD(BN_, 29); /* bias|residual|rowscale|chanscale: the attention tail */ \
     SRHIP_LD(BN_, -1);                                                  \
   } while (0)
+      if (prod != 0) {                                    // SRHIP_MATH_HALF: run-time epilogue flags
+#define SRHIP_LDH(BN_, MATH_)                                                                                       \
+  do {                                                                                                              \
+    const int nbn = cdiv(g.K, BN_);                                                                                 \
+    hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, -1, MATH_>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st,  \
+                       src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                   \
+    return check_launch("fast_conv_dma");                                                                           \
+  } while (0)
+        if (wide && prod == 1) SRHIP_LDH(128, 2);
+        if (wide) SRHIP_LDH(128, 3);
+        if (prod == 1) SRHIP_LDH(64, 2);
+        SRHIP_LDH(64, 3);
+#undef SRHIP_LDH
+      }
       if (wide) SRHIP_LDE(128);
       SRHIP_LDE(64);
 #undef SRHIP_LDE
@@ -2019,7 +2078,7 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
   g.N = n; g.Hs = ho; g.Ws = wo; g.C = cout; g.lds = ldy;
   g.KW = kw; g.Hd = h; g.Wd = w; g.dsd = stride; g.ldd = ldx; g.K = cin;
   g.ldw = kh * kw * cout; g.ldr = ldr; g.slope = slope; g.accumulate = accumulate ? 1 : 0;
-  g.flags = (residual ? SRHIP_EPI_RESIDUAL : 0) | (actmask ? SRHIP_EPI_ACTMASK : 0);
+  g.flags = (residual ? SRHIP_EPI_RESIDUAL : 0) | (actmask ? SRHIP_EPI_ACTMASK : 0) | SRHIP_EPI_GRADDATA;
   g.ss = 1; g.dhs = -1; g.dws = -1; g.khs = stride; g.kws = stride;
   g.dst_identity = stride == 1 ? 1 : 0;
   SRHIP_REQUIRE(bytes_ok((long)n * ho * wo, ldy, cout, &g.src_bytes), "conv2d_dgrad: dy tensor >= 2 GiB");
@@ -2053,7 +2112,7 @@ struct FastWgradPlan {
 int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, +10: register-staged kernel
 // row-tap kernel (wgrad_rowtap_kernel): split-bf16, 3x3 stride 1 pad 1, Cin % 64 == 0, Cout % 4 == 0 (g_wgrad_cfg 7 turns it off)
 static int rowtap_ok(int cin, int cout, int kh, int kw, int stride, int pad) {   // 0: no, 1: 128 x (kh, 64 ci), 2: 64 x (kh, 128 ci)
-  if (!(g_conv_math == 1 && g_wgrad_cfg != 7 && (g_wgrad_cfg < 10 || g_wgrad_cfg >= 100) && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout % 4 == 0))
+  if (!(g_conv_math >= 1 && g_wgrad_cfg != 7 && (g_wgrad_cfg < 10 || g_wgrad_cfg >= 100) && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout % 4 == 0))
     return 0;
   if (cout >= 128 && cin % 64 == 0) return 1;
   if (cout == 64 && cin % 128 == 0) return 2;
@@ -2074,7 +2133,7 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot, int rowtap = 0)
   }
   // split-bf16 wgrad is VALU-issue bound (every wave splits the fragments it reads): where Ktot only tiles by 64
   // (Cin = 64), a 256 x 64 tile doubles the MFMAs per split fragment (measured -10 % on 64->256 convs)
-  if (g_conv_math == 1 && g_wgrad_cfg == 0 && p.bn == 64 && cout % 256 == 0) p.bm = 256;
+  if (g_conv_math >= 1 && g_wgrad_cfg == 0 && p.bn == 64 && cout % 256 == 0) p.bm = 256;
   if (rowtap == 1) { p.bm = 128; p.bn = 192; }
   if (rowtap == 2) { p.bm = 64; p.bn = 384; }
   const long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
@@ -2132,7 +2191,10 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
 #define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                            \
-    if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 1)                                           \
+    if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 2)                                           \
+      hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16, 2>), dim3(blocks), dim3(256), 0, st, x, dy, \
+                         partial, db ? bias_partial : nullptr, g);                                               \
+    else if (!xrow && !xchan && g_wgrad_cfg < 10 && g_conv_math == 1)                                           \
       hipLaunchKernelGGL((fast_wgrad_dma_kernel<BM_, BN_, WM_, WN_, 16, 1>), dim3(blocks), dim3(256), 0, st, x, dy, \
                          partial, db ? bias_partial : nullptr, g);                                               \
     else if (!xrow && !xchan && g_wgrad_cfg < 10 && p.bk == 32)                                                        \
@@ -2148,8 +2210,14 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   if (rowtap) {
     const int nseg = cdiv(g.Wo, 16);
     const int cps = cdiv(g.N * g.Ho * nseg, p.nsplit);
-    if (rowtap == 1)
+    if (rowtap == 1 && g_conv_math == 2)
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
+                         db ? bias_partial : nullptr, g, nseg, cps);
+    else if (rowtap == 1)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
+                         db ? bias_partial : nullptr, g, nseg, cps);
+    else if (g_conv_math == 2)
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
                          db ? bias_partial : nullptr, g, nseg, cps);
     else
       hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
@@ -2170,8 +2238,12 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   int rc = check_launch("fast_wgrad");
   if (rc) return rc;
   const long total = (long)cout * g.Ktot + (db ? cout : 0);
-  hipLaunchKernelGGL(fast_wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, bias_partial, dw,
-                     db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
+  if (p.nsplit >= 256)
+    hipLaunchKernelGGL(fast_wgrad_reduce_kernel<16>, dim3(cdiv(total, 64)), dim3(1024), 0, st, partial, bias_partial, dw,
+                       db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
+  else
+    hipLaunchKernelGGL(fast_wgrad_reduce_kernel<4>, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, bias_partial, dw,
+                       db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
   return check_launch("fast_wgrad_reduce");
 }
 

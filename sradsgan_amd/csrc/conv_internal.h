@@ -25,11 +25,13 @@ bool fast_dgrad_ok(int cin, int cout, int kh, int kw);    // source channels = c
 bool fast_wgrad_ok(int cin, int cout, int kh, int kw);
 int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, hipStream_t st);
 
-// A fast packed weight holds two sections of `total` floats each:
-//   [0, total)        fp32, row = destination channel, columns (tap, source channel)        (fp32-MFMA kernels)
-//   [total, 2 total)  the same matrix pre-split for the split-bf16 kernels: every aligned group of 8 columns is
-//                     stored as 8 bf16 "hi" (round-to-nearest of v) followed by 8 bf16 "lo" (rn of v - hi), so the
-//                     two 16-byte quads a lane reads are its MFMA B operands with no conversion in the kernel
+// A fast packed weight holds three sections of `total` floats each:
+//   [0, total)         fp32, row = destination channel, columns (tap, source channel)        (fp32-MFMA kernels)
+//   [total, 2 total)   the same matrix pre-split for the split-bf16 kernels: every aligned group of 8 columns is
+//                      stored as 8 bf16 "hi" (round-to-nearest of v) followed by 8 bf16 "lo" (rn of v - hi), so the
+//                      two 16-byte quads a lane reads are its MFMA B operands with no conversion in the kernel;
+//                      the single-product bf16 arithmetic (SRHIP_MATH_HALF on gradient data) reads the hi quads only
+//   [2 total, 3 total) the same geometry with 8 fp16 values in the hi quad (lo quad zero): SRHIP_MATH_HALF fprop
 __device__ inline void fast_pack_store(float* packed, long total, long idx, float v) {
   packed[idx] = v;
   const __bf16 h = (__bf16)v;
@@ -37,6 +39,9 @@ __device__ inline void fast_pack_store(float* packed, long total, long idx, floa
   __bf16* sp = reinterpret_cast<__bf16*>(packed + total) + (idx >> 3) * 16 + (idx & 7);
   sp[0] = h;
   sp[8] = l;
+  _Float16* hp = reinterpret_cast<_Float16*>(packed + 2 * total) + (idx >> 3) * 16 + (idx & 7);
+  hp[0] = (_Float16)v;
+  hp[8] = (_Float16)0.f;
 }
 int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                     const float* rowscale, const float* chanscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,

@@ -18,7 +18,7 @@ from torch.autograd import Function
 
 from . import _hip
 
-EPI_BIAS, EPI_LRELU, EPI_RESIDUAL, EPI_ROWSCALE, EPI_CHANSCALE = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_LRELU, EPI_RESIDUAL, EPI_ROWSCALE, EPI_CHANSCALE, EPI_GRADDATA = 1, 2, 4, 8, 16, 64
 CL = torch.channels_last
 
 class _State:
@@ -97,13 +97,14 @@ def _grad_slot(p):
 # --------------------------------------------------------------------------------------------- #
 
 
-CONV_MATH_MODES = {'fp32': 0, 'bf16x3': 1}
+CONV_MATH_MODES = {'fp32': 0, 'bf16x3': 1, 'half': 2}
 
 
 def set_conv_math(mode):
-    """Arithmetic of the conv fprop/dgrad contraction (include/sradsgan_hip.h, srhip_set_conv_math): 'fp32' = fp32
-    MFMA, 'bf16x3' = split-bf16 (three bf16 MFMA products per fp32 product, fp32 accumulate).  Stands where
-    torch.backends.cudnn.allow_tf32 stands for the reference's nn.Conv2d.  Returns the previous mode."""
+    """Arithmetic of the conv contraction (include/sradsgan_hip.h, srhip_set_conv_math): 'fp32' = fp32 MFMA, 'bf16x3' =
+    split-bf16 (three bf16 MFMA products per fp32 product, fp32 accumulate), 'half' = ONE 16-bit product (fp16 for
+    activations, bf16 wherever gradients are multiplied; BASELINE configs[4], outside the 1e-3 parity contract).  Stands
+    where torch.backends.cudnn.allow_tf32 stands for the reference's nn.Conv2d.  Returns the previous mode."""
     if mode not in CONV_MATH_MODES:
         raise ValueError('conv math mode must be one of %s' % sorted(CONV_MATH_MODES))
     lib = _hip.lib()
@@ -242,7 +243,8 @@ def _out_hw(h, w, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None):
+def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None, graddata=False):
+    """graddata: x holds gradients (a second-order pass): 'half' arithmetic then rounds to bf16 instead of fp16."""
     _require_gpu(x, 'conv2d_fwd')
     x = nhwc(x)
     n, cin, h, wd = x.shape
@@ -266,6 +268,8 @@ def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=
     if chanscale is not None:
         chanscale = chanscale.contiguous()
         flags |= EPI_CHANSCALE
+    if graddata:
+        flags |= EPI_GRADDATA
     lib = _hip.lib()
     _hip.check(lib.srhip_conv2d_fwd(_p(x), _p(packed_weight(w, 0)), _p(bias), _p(residual), _p(rowscale),
                                     _p(chanscale), _p(y),
@@ -400,10 +404,10 @@ class _ConvFwd(Function):
     """y = act(conv(x, w) + b) [+ residual]   (act and residual are never combined by the model)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, stride, pad, slope):
+    def forward(ctx, x, w, b, residual, stride, pad, slope, graddata=False):
         if slope is not None and residual is not None:
             raise ValueError('conv2d: fused activation and residual are mutually exclusive')
-        y = conv2d_fwd_raw(x, w, b, stride, pad, slope, residual)
+        y = conv2d_fwd_raw(x, w, b, stride, pad, slope, residual, graddata=graddata)
         ctx.stride, ctx.pad, ctx.slope = stride, pad, slope
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.save_for_backward(x, w, y if slope is not None else None, b)
@@ -425,7 +429,7 @@ class _ConvFwd(Function):
         elif want_b:
             db = _ColSum.apply(g)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 class _ConvDgrad(Function):
@@ -441,7 +445,7 @@ class _ConvDgrad(Function):
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         skip = _skip_param_grads(w)
-        d_dy = _ConvFwd.apply(ddx, w, None, None, ctx.stride, ctx.pad, None) if ctx.needs_input_grad[0] else None
+        d_dy = _ConvFwd.apply(ddx, w, None, None, ctx.stride, ctx.pad, None, True) if ctx.needs_input_grad[0] else None
         d_w = None
         if ctx.needs_input_grad[1] and not skip and _state.direct_grads and not torch.is_grad_enabled():
             d_w, _ = wgrad_for_params(w, None, ddx, dy, ctx.stride, ctx.pad, False)   # same stream/order as every other wgrad of w
@@ -471,7 +475,7 @@ class _ConvWgrad(Function):
             if ctx.needs_input_grad[0]:
                 d_x = _ConvDgrad.apply(dy, ddw, tuple(x.shape), ctx.stride, ctx.pad)
             if ctx.needs_input_grad[1]:
-                d_dy = _ConvFwd.apply(x, ddw, None, None, ctx.stride, ctx.pad, None)
+                d_dy = _ConvFwd.apply(x, ddw, None, None, ctx.stride, ctx.pad, None, True)
         if ddb is not None and ctx.needs_input_grad[1]:
             e = ddb.view(1, -1, 1, 1).expand(dy.shape)
             d_dy = e if d_dy is None else d_dy + e

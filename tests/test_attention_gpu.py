@@ -171,10 +171,10 @@ def test_discriminator_attention_pair_first_and_second_order(b, c, h, w):
             out = _cbam_ref(xs, f1, f2, k7)
         else:
             out = ops.slam(ops.clam(xs, f1, f2), k7)
+        (g1,) = torch.autograd.grad(out, xs, dy.to(dev, dtype), retain_graph=True)
         (gx,) = torch.autograd.grad(out, xs, dy.to(dev, dtype), create_graph=True)
         pen = (gx * r.to(dev, dtype)).sum() + 0.1 * (gx * gx).sum()
         g2 = torch.autograd.grad(pen, [xs, f1, f2, k7])
-        (g1,) = torch.autograd.grad(out, xs, dy.to(dev, dtype))
         return [out.detach(), g1, gx.detach()] + list(g2)
     ref = run('cpu', torch.float64)
     got = run(DEV, torch.float32)

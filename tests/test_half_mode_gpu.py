@@ -1,0 +1,102 @@
+"""SRHIP_MATH_HALF (BASELINE configs[4], "fp16 MFMA"): one 16-bit product per multiply -- fp16 on activations, bf16 wherever
+gradients are multiplied -- with fp32 accumulation and fp32 tensors.  It is outside the 1e-3 parity contract; the bars are
+SURVEY section 7 step 10's: PSNR of the generator output within 0.05 dB of the fp32-class path and bounded loss drift over two
+training iterations, plus per-op error bounds that pin WHICH 16-bit type each pass uses."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sradsgan_ref as O
+from tests.parity_util import build_pair
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _rel(a, b):
+    b = b.double().cpu()
+    return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize('n,cin,cout,hw', [(16, 64, 256, 54), (16, 256, 64, 54), (2, 64, 64, 24)])
+def test_half_mode_conv_ops_against_fp64(n, cin, cout, hw):
+    """fprop rounds to fp16 (11-bit significand: ~3e-4 of the output scale), dgrad / wgrad and GRADDATA-flagged fprop
+    to bf16 (8 bits: ~3e-3); gradient-sized data (1e-7) must survive, i.e. the gradient passes cannot be fp16."""
+    import torch.nn.functional as F
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, hw, hw, generator=g) * 1e-7                  # mean-reduced-loss sized gradients
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, b.double(), padding=1)
+    yd.backward(dy.double())
+    xh = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    dyh = dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    wp = torch.nn.Parameter(w.to(DEV))
+    with ops.conv_math('half'):
+        y = ops.conv2d_fwd_raw(xh, wp, b.to(DEV), 1, 1)
+        yg = ops.conv2d_fwd_raw(xh * 1e-7, wp, None, 1, 1, graddata=True)
+        dx = ops.conv2d_dgrad_raw(dyh, wp, tuple(x.shape), 1, 1)
+        dw, db = ops.conv2d_wgrad_raw(xh, dyh, tuple(w.shape), 1, 1, True)
+    with ops.conv_math('bf16x3'):
+        y3 = ops.conv2d_fwd_raw(xh, wp, b.to(DEV), 1, 1)
+    e_f, e_3 = _rel(y, yd.detach()), _rel(y3, yd.detach())
+    e_g = _rel(yg, (yd.detach() - b.double().view(1, -1, 1, 1)) * 1e-7)
+    e_dx, e_dw, e_db = _rel(dx, xd.grad), _rel(dw, wd.grad), _rel(db, dy.double().sum((0, 2, 3)))
+    print('half mode %dx%d->%d @%d: fprop %.2e (bf16x3 %.2e)  graddata fprop %.2e  dgrad %.2e  wgrad %.2e  db %.2e'
+          % (n, cin, cout, hw, e_f, e_3, e_g, e_dx, e_dw, e_db))
+    assert e_3 < 2e-5 < e_f < 1.5e-3                     # really a 16-bit product, and fp16-sized
+    assert e_g < 1.5e-2 and e_dx < 1.5e-2 and e_dw < 1.5e-2 and e_db < 1e-5      # bf16-sized, no underflow at 1e-7
+
+
+def test_half_mode_generator_psnr_within_0p05_db():
+    """Full x4 generator (12 x 3, 54 -> 216): PSNR / ERGAS of the uint8-quantised output against a synthetic HR target in
+    'half' arithmetic vs the default split-bf16 path (which is pinned to the reference at 1e-3)."""
+    from sradsgan_amd import model as M, ops
+    og = O.GeneratorResNet(O.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=4)
+    O.det_init_(og, prefix='G.')
+    hg = M.GeneratorResNet(M.ResGroup, n_residual_blocks=12, n_basic_blocks=3, upscale_factor=4)
+    hg.load_state_dict(og.state_dict(), strict=True)
+    hg.to(DEV).eval()
+    lr = O.det_fill('psnr.lr', (2, 3, 54, 54), 0.5, 0.5).to(DEV)
+    hr = O.det_fill('psnr.hr', (2, 3, 216, 216), 0.5, 0.5)
+    with torch.no_grad():
+        y3 = hg(lr).cpu()
+        with ops.conv_math('half'):
+            ops.repack_all()
+            yh = hg(lr).cpu()
+    rel = float((yh - y3).abs().max() / y3.abs().max())
+    for b in range(2):
+        tgt = O.to_uint8_hwc(hr[b])
+        p3, ph = O.psnr_u8(tgt, O.to_uint8_hwc(y3[b])), O.psnr_u8(tgt, O.to_uint8_hwc(yh[b]))
+        print('half mode generator: image %d PSNR %.4f dB (split-bf16 %.4f), output rel diff %.2e' % (b, ph, p3, rel))
+        assert abs(ph - p3) < 0.05
+    assert 1e-5 < rel < 2e-2
+
+
+def test_half_mode_two_training_iterations_drift():
+    """Two iterations of the small step in 'half' arithmetic against the same step in the default arithmetic: finite
+    losses, scalars within 2 % (the gradient penalty, a second-order quantity, is the loosest), and weights that moved."""
+    from sradsgan_amd import ops
+    from sradsgan_amd.train_step import TrainStep
+    names = ['loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp']
+    res = {}
+    for mode in ('bf16x3', 'half'):
+        with ops.conv_math(mode):
+            (hg, hd, hf), _ = build_pair(2, 2, 4, DEV)
+            step = TrainStep(hg, hd, hf)
+            scal = []
+            for it in range(2):
+                lr_img = O.det_fill('half.lr.%d' % it, (4, 3, 24, 24), 0.5, 0.5).to(DEV)
+                hr_img = O.det_fill('half.hr.%d' % it, (4, 3, 96, 96), 0.5, 0.5).to(DEV)
+                alpha = O.det_fill('half.alpha.%d' % it, (4, 1, 1, 1), 0.5, 0.5).to(DEV)
+                out = step(lr_img, hr_img, alpha)
+                scal.append(np.array([float(out[k]) for k in names]))
+            res[mode] = scal
+    for it in range(2):
+        a, b = res['half'][it], res['bf16x3'][it]
+        print('half mode it %d: %s  vs default %s' % (it, a, b))
+        assert np.all(np.isfinite(a))
+        assert float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) < 2e-2

@@ -24,6 +24,17 @@ def main(path, top=45):
         a[0] += 1
         a[1] += e - s
     tot = sum(v[1] for v in agg.values())
+    for col in ('queue_id', 'stream_id'):                   # per hardware queue / stream: busy time and span
+        if col in cols:
+            per = {}
+            for q, s_, e_ in c.execute('select %s, start, end from kernels' % col).fetchall():
+                a = per.setdefault(q, [0, 0, None, None])
+                a[0] += 1
+                a[1] += e_ - s_
+                a[2] = s_ if a[2] is None else min(a[2], s_)
+                a[3] = e_ if a[3] is None else max(a[3], e_)
+            for q, (cnt, busy, s0, e0) in sorted(per.items(), key=lambda kv: -kv[1][1])[:8]:
+                print('# %s %s: %d kernels, busy %.1f ms over a span of %.1f ms' % (col, q, cnt, busy / 1e6, (e0 - s0) / 1e6))
     print('# kernels: %d dispatches, %.3f ms total GPU kernel time' % (len(rows), tot / 1e6))
     print('%-9s %-11s %-10s %-6s %s' % ('calls', 'total_ms', 'avg_us', 'pct', 'kernel'))
     for n, (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:

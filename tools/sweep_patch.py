@@ -11,7 +11,7 @@ x = torch.randn(B, 64, 54, 54, device=dev).contiguous(memory_format=torch.channe
 w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=dev) * 0.05)
 b = torch.randn(256, device=dev) * 0.01
 fl = 2.0 * B * 54 * 54 * 256 * 64 * 9
-names = {0: 'shipped', 1: 'setprio', 2: 'no convert (timing only)', 4: 'buffer DMA', 5: 'buffer DMA + setprio',
+names = {16: 'prefetched fragments (2 blocks per CU)', 20: 'prefetched fragments + buffer DMA', 0: 'shipped', 1: 'setprio', 2: 'no convert (timing only)', 4: 'buffer DMA', 5: 'buffer DMA + setprio',
          6: 'buffer DMA, no convert (timing only)', 8: 'no stores (timing only)', 15: 'all'}
 variants = [int(v) for v in os.environ.get('VARS', '0,1,2,4,5,6,8').split(',')]
 fn = lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
