@@ -45,7 +45,8 @@ int srhip_abi_version(void);
  * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added. */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
- *          20 register-staged kernels only, 21 no patch kernel, 1..8 fixed tile shapes of the register-staged kernel
+ *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
+ *          1..8 fixed tile shapes of the register-staged kernel
  *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, >= 10 register-staged
  *          kernel, >= 100 split-K block target of the row-tap kernel
  *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (0x100 / 0x200: timing only, wrong results;

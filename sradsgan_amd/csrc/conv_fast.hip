@@ -1926,14 +1926,17 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   const bool al16 = g.K % 4 == 0 && g.ldd % 4 == 0 && ((uintptr_t)dst & 15) == 0 && (!residual || (g.ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   // stride-1 3x3 in split-bf16: the patch kernel (g_fast_cfg 21 turns it off, -2 forces it at any size)
-  if (g_conv_math >= 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+  bool patch_to_dma = false;             // g_fast_cfg 23: every launch the patch kernel would take goes to the (bit-identical) DMA kernel
+  if (g_conv_math >= 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && (g_fast_cfg < 1 || g_fast_cfg == 23) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       !(eflags & (SRHIP_EPI_CHANSCALE | SRHIP_EPI_ROWSCALE)) && !g.accumulate) {
     PatchGeom pg;
     if (plan_patch(g, &pg)) {
       const int nbm = g.N * pg.tiles_h * pg.tiles_w;
       const bool wide = g.K >= 128;
       const int nbn = cdiv(g.K, wide ? 128 : 64);
-      if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
+      if (g_fast_cfg == 23) {
+        patch_to_dma = (long)nbm * nbn >= 256;
+      } else if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
         const float* wsplit = w16;
         if (prod != 0) {                                  // SRHIP_MATH_HALF: run-time epilogue flags keep the variant count down
 #define SRHIP_LPH(BN_, PROD_)                                                                                       \
@@ -1970,10 +1973,10 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       }
     }
   }
-  if (g_fast_cfg != 20 && g_fast_cfg < 1 && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+  if (g_fast_cfg != 20 && (g_fast_cfg < 1 || g_fast_cfg == 23) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       (!(eflags & SRHIP_EPI_CHANSCALE) || ((uintptr_t)chanscale & 15) == 0)) {
     const int nbm = cdiv(g.M, 128);
-    const bool force = g_fast_cfg == -1;                 // tests: take the DMA kernels at any problem size
+    const bool force = g_fast_cfg == -1 || patch_to_dma;   // tests: take the DMA kernels at any problem size
     // fp32: the register-staged kernel wins below ~2 tiles per CU; split-bf16: its fp32 MFMAs cost 5x more than
     // the DMA kernel's, so the DMA kernel is taken from half a wave of tiles on
     const long min_tiles = g_conv_math >= 1 ? 128 : 512;

@@ -47,7 +47,9 @@ def test_half_mode_conv_ops_against_fp64(n, cin, cout, hw):
     e_dx, e_dw, e_db = _rel(dx, xd.grad), _rel(dw, wd.grad), _rel(db, dy.double().sum((0, 2, 3)))
     print('half mode %dx%d->%d @%d: fprop %.2e (bf16x3 %.2e)  graddata fprop %.2e  dgrad %.2e  wgrad %.2e  db %.2e'
           % (n, cin, cout, hw, e_f, e_3, e_g, e_dx, e_dw, e_db))
-    assert e_3 < 2e-5 < e_f < 1.5e-3                     # really a 16-bit product, and fp16-sized
+    assert e_3 < 2e-5 and e_f < 1.5e-3                   # fp16-sized at worst
+    if n * hw * hw >= 128 * 128:                         # (very small grids run the exact-fp32 kernels in every mode)
+        assert e_f > 2e-5 and e_dx > 2e-5                # really ONE 16-bit product
     assert e_g < 1.5e-2 and e_dx < 1.5e-2 and e_dw < 1.5e-2 and e_db < 1e-5      # bf16-sized, no underflow at 1e-7
 
 

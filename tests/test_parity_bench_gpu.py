@@ -3,7 +3,9 @@
 (i)  the full 12 x 3 generator, 54 -> 216, at a batch where `bench.py`'s kernels are the ones selected (B = 12:
      288 patch tiles per conv => conv_patch_kernel / wgrad_rowtap_kernel, not the small-grid LDS-DMA kernels the B = 2
      full-size test reaches): two training iterations against the CPU oracle AND against the same step forced onto the
-     already pinned kernel family (srhip_debug_set(0, -1): LDS-DMA fprop/dgrad, (1, 7): generic split-K wgrad);
+     already pinned kernel family (srhip_debug_set(0, 23): no patch kernel => LDS-DMA fprop/dgrad, (1, 7): generic
+     split-K wgrad; key 0 value -1 would also push the attention MLP's 24-row convs from the exact-fp32 small-grid
+     kernel onto split-bf16 and so change arithmetic, not just kernels);
 (ii) generator forward + backward at the real LR tile of every other scale of BASELINE configs[4]
      (x2: 108, x3: 72, x8: 27, x9: 24): SGAM at N = 11664, the r = 3 two-stage up-sampler, odd 27 x 27 maps;
 (iii) post-step weights against the vectors recorded from the reference (train_full.npz G_after__* / D_after__*) and
@@ -59,7 +61,7 @@ def test_bench_configuration_step_b12_against_oracle_and_pinned_kernels():
     scal, grads, (hg, hd) = _run_hip(B, 2, tag)
     # the same job on the kernel family the small tests pin (bit-identical fprop/dgrad by construction; the generic
     # split-K wgrad sums in a different order)
-    scal_p, grads_p, _ = _run_hip(B, 2, tag, debug=((0, -1), (1, 7)))
+    scal_p, grads_p, _ = _run_hip(B, 2, tag, debug=((0, 23), (1, 7)))
     for it in range(2):
         d = float(np.abs(scal[it] - scal_p[it]).max())
         print('b12 it %d: scalars vs pinned kernels max diff %.3e' % (it, d))
