@@ -205,8 +205,11 @@ class TrainStep:
             with ops.backward_scope(stop_at=(gen_hr,)):
                 torch.autograd.backward(total, inputs=d_params)
         self._exchange_start('D')
-        return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
-                    content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+        out = dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
+                   content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+        if os.environ.get('SRHIP_STEP_DEBUG') == '1':
+            out['d_gen'] = d_gen.detach()
+        return out
 
     def _adam(self, arena, lr, clip, scale):
         _hip.check(_hip.lib().srhip_adam_step(_ptr(arena.flat_p), _ptr(arena.flat_g), _ptr(arena.exp_avg),
@@ -242,7 +245,8 @@ class TrainStep:
             self._graph.enable_debug_mode()
         self._capturing = True
         try:
-            with torch.cuda.graph(self._graph):
+            # same arithmetic as the eager path: weight-gradient kernels accumulate straight into the arenas, in program order
+            with torch.cuda.graph(self._graph), ops.direct_param_grads(None):
                 self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
         finally:
             self._capturing = False
@@ -266,7 +270,7 @@ class TrainStep:
             # stream capture); it is a real iteration, not a discarded one
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), ops.direct_param_grads(None):
                 out = self._compute(imgs_lr, imgs_hr, alpha)
                 self._update()
             torch.cuda.current_stream().wait_stream(side)
