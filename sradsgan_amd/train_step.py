@@ -55,7 +55,8 @@ class TrainStep:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = self.arena_G.flat_p.device
         self._wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda') else None
-        self._d_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
+        d_prio = -1 if os.environ.get('SRHIP_D_PRIO') == '1' else 0     # experiment knob: discriminator stream at high priority
+        self._d_stream = torch.cuda.Stream(device=dev, priority=d_prio) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._capturing = False
@@ -146,19 +147,26 @@ class TrainStep:
             imgs_hr.record_stream(side)
         gen_hr = G(imgs_lr)
         pixel = ops.l1_mean(gen_hr, imgs_hr)
-        if side is None:
-            with torch.no_grad():
-                real_feat = F(imgs_hr)
-        else:
+        early = os.environ.get('SRHIP_LATE_JOIN', '1') != '1' and side is not None     # A/B knob (old order)
+        if early:
             torch.cuda.current_stream().wait_stream(side)
-            real_feat.record_stream(torch.cuda.current_stream())   # allocated in the side stream's pool, read here
-        content = ops.l1_mean(F(gen_hr), real_feat)
+        fake_feat = F(gen_hr)
         stash = []
         for bn in self._bns:
             bn._stat_stash = stash
         d_gen = D(gen_hr)                                         # running-stat update #1
         for bn in self._bns:
             bn._stat_stash = None
+        # the real batch's features are needed only now: joining the side stream here instead of right after the generator's
+        # forward removes a 6 ms stall of the main stream (the side stream's VGG pass shares the GPU with G's forward and
+        # finishes ~6 ms after it; profiles/r02_step_eager_kernel_stats.txt)
+        if side is None:
+            with torch.no_grad():
+                real_feat = F(imgs_hr)
+        else:
+            torch.cuda.current_stream().wait_stream(side)
+            real_feat.record_stream(torch.cuda.current_stream())   # allocated in the side stream's pool, read here
+        content = ops.l1_mean(fake_feat, real_feat)
         loss_gan = -ops.mean(d_gen)
         loss_G = pixel + self.weight_content * content + self.weight_gan * loss_gan
 

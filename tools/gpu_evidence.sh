@@ -1,17 +1,23 @@
 #!/bin/bash
-# Round evidence in one call: default bench line (with cpu_baseline), fp32-mode line, inference line, single-rank RCCL
-# line, whole-step kernel stats (rocprofv3), roofline kernel-trace + PMC passes for both conv arithmetic modes.
+# Round evidence in one call: default bench line (with cpu_baseline), fp32-mode line, half-mode line, inference line, chain
+# line, single-rank RCCL line, whole-step kernel stats (rocprofv3), roofline kernel-trace + PMC passes per conv arithmetic mode.
 R=$GRAFT_REPO_ROOT
 E=$R/gpurun_out/evidence
 mkdir -p $E
 cd $R
 timeout 900 python bench.py > $E/bench_n1.log 2>&1; tail -1 $E/bench_n1.log > $E/bench_n1.json; cut -c1-260 $E/bench_n1.json
 timeout 600 python bench.py --no-cpu-baseline --conv-math fp32 2>&1 | tail -1 > $E/bench_n1_fp32.json; cut -c1-200 $E/bench_n1_fp32.json
+timeout 600 python bench.py --no-cpu-baseline --conv-math half 2>&1 | tail -1 > $E/bench_n1_half.json; cut -c1-200 $E/bench_n1_half.json
 timeout 600 python bench.py --workload infer 2>&1 | tail -1 > $E/bench_infer.json; cut -c1-260 $E/bench_infer.json
+timeout 900 python bench.py --workload chain 2>&1 | tail -1 > $E/bench_chain_half.json; cut -c1-300 $E/bench_chain_half.json
+timeout 900 python bench.py --workload chain --conv-math bf16x3 2>&1 | tail -1 > $E/bench_chain_bf16x3.json; cut -c1-300 $E/bench_chain_bf16x3.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $E/bench_n1_rccl_single_rank.json; cut -c1-200 $E/bench_n1_rccl_single_rank.json
+timeout 600 python bench.py --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_again.json; cut -c1-200 $E/bench_n1_again.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
 cd $R
-f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 60 > $E/step_kernel_stats.txt; head -12 $E/step_kernel_stats.txt
-bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -9 $E/roofline2.log
+f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 70 > $E/step_kernel_stats.txt; head -14 $E/step_kernel_stats.txt
+bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -12 $E/roofline2.log
+cp $R/gpurun_out/roof2/summary.txt $E/roofline_pmc_summary.txt; cp $R/gpurun_out/roof2/roofline_traffic.json $E/roofline_traffic.json
+for M in fp32 bf16x3 half; do f=$(find $R/gpurun_out/roof2/$M/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $E/roofline_only_${M}_kernel_stats.csv; done
 rm -rf $E/step/*.db

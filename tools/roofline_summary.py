@@ -13,7 +13,7 @@ def short(n):
     return re.sub(r'\(.*', '', n.replace('void ', ''))[:70]
 
 
-for mode in ('fp32', 'bf16x3'):
+for mode in ('fp32', 'bf16x3', 'half'):
     d = os.path.join(root, mode)
     if not os.path.isdir(d):
         continue
