@@ -344,7 +344,16 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
             if t is not None:
                 t.record_stream(side)
         return None, None
-    return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
+    dw, db = conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
+    if gw is not None and (db is None or gb is not None):
+        # Shapes the accumulating kernel does not take (the 3- and 2-channel convs): add in program order here rather than
+        # through autograd's AccumulateGrad, whose order among several contributions to one parameter follows per-thread
+        # node counters (the first step of a process differs from later ones by an ulp, tests/test_graph_gpu.py).
+        gw.add_(dw)
+        if db is not None:
+            gb.add_(db)
+        return None, None
+    return dw, db
 
 
 def colsum_raw(dy):

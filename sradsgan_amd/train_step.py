@@ -101,18 +101,31 @@ class TrainStep:
         self._set_d_grad(True)
         self.arena_D.zero_grad()
         fake = gen_hr.detach()
-        loss_D = -ops.mean(D(imgs_hr)) + ops.mean(D(fake))
+        terms = [-ops.mean(D(imgs_hr)), ops.mean(D(fake))]
+        loss_D = terms[0] + terms[1]
         if self.use_gp:
             gp = self.gradient_penalty(imgs_hr, fake, alpha)
-            total = loss_D + (1.0 + self.lambda_gp) * gp          # :639 + :884-886 => 1 + lambda
+            terms.append((1.0 + self.lambda_gp) * gp)             # :639 + :884-886 => 1 + lambda
             loss_D = loss_D + self.lambda_gp * gp
         else:
             gp = torch.zeros((), device=imgs_hr.device)
-            total = loss_D
-        total.backward()
+        self._backward_terms(terms)
         self._exchange_start('D')
         return dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                     content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)
+
+    @staticmethod
+    def _backward_terms(terms, inputs=None):
+        """loss_D.backward() (sradsgan.py:886) as one backward per term of the sum, in program order.  A single call over
+        the sum lets the autograd engine interleave the nodes of the real pass, the fake pass and the penalty's double
+        backward by their sequence numbers -- and those come from two per-thread counters (forward nodes are numbered by
+        the calling thread, the nodes autograd.grad(create_graph=True) creates by the engine's device thread), so which of
+        the four contributions to a discriminator weight is added first depended on how much autograd work the process
+        had done before (an ulp in D's gradients; tools/check_graph4.py).  Term by term the order is fixed: inside one
+        term the nodes of one thread are ordered by creation, and the penalty's two contributions to a weight (through
+        the first-order backward's node, then through the forward node) are ordered by data dependence."""
+        for t in terms:
+            torch.autograd.backward(t, inputs=inputs)
 
     def _exchange_start(self, which):
         """Hands a finished gradient arena to the exchange (dp.GradSync.start): called right after the backward that
@@ -172,17 +185,17 @@ class TrainStep:
 
         def d_forward():
             # ---------------- discriminator forward passes (sradsgan.py:865-884) ----------------
-            loss_D = -ops.mean(D(imgs_hr)) + ops.mean(d_gen)      # update #2 (real)
+            terms = [-ops.mean(D(imgs_hr)), ops.mean(d_gen)]      # update #2 (real)
+            loss_D = terms[0] + terms[1]
             ops.replay_bn_update(stash)                           # update #3 (the fake pass that is not recomputed)
             fake = gen_hr.detach()
             if self.use_gp:
                 gp = self.gradient_penalty(imgs_hr, fake, alpha)  # update #4
-                total = loss_D + (1.0 + self.lambda_gp) * gp      # :639 + :884-886 => 1 + lambda
+                terms.append((1.0 + self.lambda_gp) * gp)         # :639 + :884-886 => 1 + lambda
                 loss_D = loss_D + self.lambda_gp * gp
             else:
                 gp = torch.zeros((), device=imgs_hr.device)
-                total = loss_D
-            return loss_D, gp, total, fake
+            return loss_D, gp, terms, fake
 
         if side is not None and self.overlap_d_step:
             # The discriminator's real / interpolate passes (incl. the first-order backward of the penalty) depend
@@ -193,14 +206,14 @@ class TrainStep:
             dside = self._d_stream if self._d_stream is not None else side   # third stream: the D passes beside G's dgrads (main) and the wgrads (side)
             dside.wait_stream(main)                               # gen_hr, d_gen and running-stat update #1 are in
             with torch.cuda.stream(dside):
-                loss_D, gp, total, fake = d_forward()
+                loss_D, gp, terms, fake = d_forward()
             for t in (gen_hr, d_gen, alpha):
                 t.record_stream(dside)
             with ops.backward_scope(skip_params=d_params):        # no discriminator wgrads in the G step (:857 -> :865)
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
             self._exchange_start('G')                             # G's gradients travel under the whole D step
             with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
-                torch.autograd.backward(total, inputs=d_params)
+                self._backward_terms(terms, d_params)
             main.wait_stream(dside)
             main.wait_stream(side)
             for t in (loss_D, gp):
@@ -209,9 +222,9 @@ class TrainStep:
             with ops.backward_scope(skip_params=d_params):
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
             self._exchange_start('G')
-            loss_D, gp, total, fake = d_forward()
+            loss_D, gp, terms, fake = d_forward()
             with ops.backward_scope(stop_at=(gen_hr,)):
-                torch.autograd.backward(total, inputs=d_params)
+                self._backward_terms(terms, d_params)
         self._exchange_start('D')
         out = dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),
                    content=content.detach(), loss_gan=loss_gan.detach(), gp=gp.detach(), gen_hr=fake)

@@ -43,12 +43,10 @@ def _run(use_graph, iters, sync_at):
 
 
 def test_graph_replay_is_independent_of_host_syncs_and_tracks_eager():
-    # One throw-away run first.  The three discriminator parameters whose weight gradients still go through autograd's
-    # AccumulateGrad (3- and 2-channel convs: model.0, model.18.conv1) receive four contributions per iteration, added in
-    # the autograd engine's node order; that order depends on per-thread node counters and differs between the FIRST step
-    # of a process and every later one (1 ulp in those gradients, tools/check_graph3.py).  It is an eager-mode property
-    # of the engine, frozen at capture time in graph mode, and unrelated to what this test is after.
-    _run(False, 2, set())
+    # No warm-up run and no fresh process needed: TrainStep backpropagates loss_D term by term, which pins the order in
+    # which the four contributions to a discriminator weight are added (train_step._backward_terms; before that the
+    # order followed autograd's two per-thread node counters and with them the process's history -- an ulp in D's
+    # gradients between graph and eager whenever other autograd work had run first, tools/check_graph4.py).
     iters = 52
     sync_at = {1, 2} | set(range(7, iters, 7))
     synced_s, synced_w = _run(True, iters, sync_at)
