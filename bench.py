@@ -38,6 +38,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 PER_GPU_BATCH = 32
 SCALE, LR_SIDE = 4, 54
+NOMINAL_SCLK_MHZ = 2400.0              # the shader clock the guide's dense peaks are quoted at
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 # conv arithmetic (include/sradsgan_hip.h srhip_set_conv_math): 'bf16x3' spends three bf16 MFMA products per fp32
@@ -112,6 +113,70 @@ def build_networks(device, seed):
     return G.to(device), D.to(device), F.to(device)
 
 
+class PowerSampler:
+    """Board power and shader clock of one GPU from the amdgpu hwmon files (power1_input in uW, freq1_input in Hz), sampled by
+    a thread every 20 ms.  The conv kernels of this path run into the board's power cap (1400 W): the shader clock drops
+    from 2.4 GHz to ~1.7 GHz under them (profiles/r02_power_clock_probe.txt), so a roofline fraction quoted against the
+    nominal-clock peak is bounded by that, and the line says so with numbers."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        self.dir = None
+        cands = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_input'))
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = '%04x:%02x:%02x' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        for c in cands:
+            hw = os.path.dirname(c)
+            pci = os.path.basename(os.path.realpath(os.path.join(hw, '..', '..')))
+            if want is not None and pci.lower().startswith(want):
+                self.dir = hw
+        if self.dir is None and len(cands) == 1:
+            self.dir = os.path.dirname(cands[0])
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self._read('freq1_input') / 1e6, self._read('power1_input') / 1e6))
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(0.02)
+
+    def __enter__(self):
+        if self._thread is not None:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        f = [a for a, _ in self.samples]
+        w = [b for _, b in self.samples]
+        try:
+            cap = self._read('power1_cap') / 1e6
+        except (OSError, ValueError):
+            cap = None
+        return {'sclk_mhz_mean': round(sum(f) / len(f), 0), 'sclk_mhz_min': round(min(f), 0), 'watts_mean': round(sum(w) / len(w), 0),
+                'watts_max': round(max(w), 0), 'power_cap_w': cap, 'nominal_sclk_mhz': NOMINAL_SCLK_MHZ, 'samples': len(f)}
+
+
 def _time_launches(fn, iters=50):
     import torch
     for _ in range(5):
@@ -180,11 +245,28 @@ def time_dominant_kernel(device, batch):
         iso = _time_isolated(fn)
         ms = max(b2b, iso)
         achieved = flops / (ms * 1e-3) / 1e12
-        out.append({'bound': 'mfma', 'kernel': kernel, 'conv_math': math, 'achieved': round(achieved, 2),
-                    'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                    'traffic': traffic.get(key), 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4),
-                    'back_to_back_launch_ms': round(b2b, 4), 'isolated_launch_ms': round(iso, 4),
-                    'dtype_peak': peak_name})
+        rec = {'bound': 'mfma', 'kernel': kernel, 'conv_math': math, 'achieved': round(achieved, 2),
+               'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+               'traffic': traffic.get(key), 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4),
+               'back_to_back_launch_ms': round(b2b, 4), 'isolated_launch_ms': round(iso, 4),
+               'dtype_peak': peak_name}
+        # the same launch looped for ~1.2 s with the board's power and shader clock sampled: `peak` assumes the nominal
+        # clock, the kernel runs at whatever clock the 1400 W cap leaves (extra keys, not part of frac)
+        with PowerSampler(device.index or 0) as ps:
+            t_end = time.perf_counter() + 1.2
+            n = 0
+            while time.perf_counter() < t_end:
+                for _ in range(100):
+                    fn()
+                torch.cuda.synchronize()
+                n += 100
+            sus = (time.perf_counter() - (t_end - 1.2)) / n * 1e3
+        pw = ps.summary()
+        if pw is not None:
+            pw['sustained_launch_ms'] = round(sus, 4)
+            pw['frac_of_peak_at_sustained_clock'] = round(flops / (sus * 1e-3) / 1e12 / (peak * pw['sclk_mhz_mean'] / NOMINAL_SCLK_MHZ), 4)
+        rec['power'] = pw
+        out.append(rec)
     return out[0], out[1]
 
 
@@ -544,6 +626,8 @@ def main():
             torch.cuda.synchronize()
     if os.environ.get('BENCH_NO_WARM_BARRIER') != '1':
         barrier()
+    sampler = PowerSampler(local_rank)                           # a thread reading two sysfs files every 20 ms
+    sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(lr, hr, alpha)
@@ -553,6 +637,7 @@ def main():
             torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    sampler.__exit__()
     if trace:
         print('losses per step:', ' '.join('%d:%.4g/%.4g' % (i, float(t['loss_G']), float(t['loss_D']))
                                            for i, t in enumerate(trace)), file=sys.stderr)
@@ -602,6 +687,7 @@ def main():
             'step_frac_of_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (MATH_PEAK[conv_math][0] * world), 4),
         }
         line['config']['conv_math'] = conv_math
+        line['power'] = sampler.summary()                       # board power / shader clock over the timed region (rank 0's GPU)
         if sync is not None:
             line['rccl_ranks'] = sync.rccl_ranks()             # size of the communicator the gradients really went through
             line['exchange'] = 'srhip_dp_allreduce_bucket on a dedicated HIP stream, G arena under the D step'

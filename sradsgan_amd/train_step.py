@@ -60,6 +60,8 @@ class TrainStep:
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._capturing = False
+        self._timeline_on = os.environ.get('SRHIP_STEP_TIMELINE') == '1'
+        self.timeline = []
         self._calls = 0
         self._static = None
         self._d_params = self.arena_D.params
@@ -68,6 +70,13 @@ class TrainStep:
         ops.mark_static(self.F)
 
     # ------------------------------------------------------------------------------------------ #
+    def _mark(self, name, stream=None):
+        """SRHIP_STEP_TIMELINE=1: a timing event on `stream` (default: current), kept in self.timeline for tools/step_timeline.py."""
+        if self._timeline_on:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.timeline.append((self._calls, name, ev))
+
     def _set_d_grad(self, flag):
         for p in self._d_params:
             p.requires_grad_(flag)
@@ -158,7 +167,9 @@ class TrainStep:
             with torch.cuda.stream(side), torch.no_grad():
                 real_feat = F(imgs_hr)
             imgs_hr.record_stream(side)
+        self._mark('start')
         gen_hr = G(imgs_lr)
+        self._mark('G fwd done')
         pixel = ops.l1_mean(gen_hr, imgs_hr)
         early = os.environ.get('SRHIP_LATE_JOIN', '1') != '1' and side is not None     # A/B knob (old order)
         if early:
@@ -204,16 +215,38 @@ class TrainStep:
             # node on the stream of its forward, so their double backward stays on the side stream too.
             main = torch.cuda.current_stream()
             dside = self._d_stream if self._d_stream is not None else side   # third stream: the D passes beside G's dgrads (main) and the wgrads (side)
-            dside.wait_stream(main)                               # gen_hr, d_gen and running-stat update #1 are in
+            self._mark('fwd done (VGG, D(gen), losses)')
+            late = os.environ.get('SRHIP_D_FWD_FIRST', '0') != '1'          # A/B knob: '1' restores the old enqueue order
+            if late:
+                # The HOST enqueues the generator's backward first and the D passes second; the D stream waits only for the
+                # forward (event), so its kernels still run beside the generator's backward.  With a slow host (under a
+                # profiler) the ~440 launches of the D passes enqueued first left the main stream dry for 6.6 ms per step;
+                # at full host speed the two orders time the same (tools/step_timeline.py).
+                fwd_done = torch.cuda.Event()
+                fwd_done.record(main)
+                with ops.backward_scope(skip_params=d_params):    # no discriminator wgrads in the G step (:857 -> :865)
+                    torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+                self._exchange_start('G')                         # G's gradients travel under the whole D step
+                self._mark('G bwd done (main)')
+                self._mark('G wgrads done (wgrad stream)', side)
+                dside.wait_event(fwd_done)                        # gen_hr, d_gen and running-stat update #1 are in
+            else:
+                dside.wait_stream(main)
+            self._mark('D passes begin (D stream)', dside)
             with torch.cuda.stream(dside):
                 loss_D, gp, terms, fake = d_forward()
+            self._mark('D passes + GP first order done (D stream)', dside)
             for t in (gen_hr, d_gen, alpha):
                 t.record_stream(dside)
-            with ops.backward_scope(skip_params=d_params):        # no discriminator wgrads in the G step (:857 -> :865)
-                torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
-            self._exchange_start('G')                             # G's gradients travel under the whole D step
+            if not late:
+                with ops.backward_scope(skip_params=d_params):
+                    torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
+                self._exchange_start('G')
             with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
                 self._backward_terms(terms, d_params)
+            self._mark('D bwd done (main)')
+            self._mark('D bwd done (D stream)', dside)
+            self._mark('wgrads done (wgrad stream)', side)
             main.wait_stream(dside)
             main.wait_stream(side)
             for t in (loss_D, gp):
@@ -256,6 +289,7 @@ class TrainStep:
             gs.finish('D')
         self._adam(self.arena_D, self.lr_D, self.clip_value, scale)
         ops.bump_weight_epoch()
+        self._mark('update done')
 
     # ------------------------------------------------------------------------------------------ #
     def _capture(self, imgs_lr, imgs_hr, alpha):
