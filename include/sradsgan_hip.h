@@ -47,7 +47,7 @@ int srhip_abi_version(void);
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
  *          1..8 fixed tile shapes of the register-staged kernel
- *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, >= 10 register-staged
+ *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, 9 row-tap kernel without paired row tails, >= 10 register-staged
  *          kernel, >= 100 split-K block target of the row-tap kernel
  *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (0x100 / 0x200: timing only, wrong results;
  *          0x400: plain instead of non-temporal epilogue stores, correct results) */

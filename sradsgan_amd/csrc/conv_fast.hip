@@ -1526,7 +1526,13 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
 template <int BM, int CIS, bool SPLIT = true>     // SPLIT false: one bf16 product per multiply (SRHIP_MATH_HALF)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_rowtap_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    float* __restrict__ bias_partial, WgradGeom g, int nseg, int chunks_per_split) {
+    float* __restrict__ bias_partial, WgradGeom g, int nseg, int chunks_per_split, int tail_rem) {
+  // tail_rem > 0 ("paired tails", rows of 16 q + tail_rem pixels with tail_rem <= 8): the chunks are enumerated per PAIR of
+  // image rows -- q full 16-pixel segments of row A, q of row B, then ONE chunk that holds both rows' tails: MFMA K index
+  // k < 8 is pixel 16 q + k of row A, k >= 8 pixel 16 q + (k - 8) of row B (slots past the tail carry dy = 0).  Each half
+  // is staged with its own halo (staged rows 0..9 / 10..19), so a lane's gather only swaps the base row of its K half
+  // (8 khalf -> 10 khalf).  54-pixel rows: 7 chunks per two rows instead of 8 (an eighth of the MFMAs, DMAs and splits
+  // of the 4 x 16 layout fell on padding).
   // tile = BM output channels x (one kh, CIS input channels, three kw); 128 x 64 for wide layers, 64 x 128 for Cout = 64
   constexpr int WM = BM / 64, WN = 4 / WM;          // a wave owns 64 co x (3 kw x 32 ci)
   constexpr int NCI = CIS / WN;
@@ -1567,7 +1573,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   const int m0 = tile_m * BM, ci_base = cs * CIS;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
-  const int nchunks_total = g.N * g.Ho * nseg;
+  const int q = g.Wo >> 4;                          // full segments per row (paired-tails mode)
+  const int cpp = 2 * q + 1;                        // chunks per row pair
+  const int rows_total = g.N * g.Ho;
+  const int nchunks_total = tail_rem > 0 ? ((rows_total + 1) >> 1) * cpp : g.N * g.Ho * nseg;
   const int c_begin = split * chunks_per_split;
   const int c_end = min(c_begin + chunks_per_split, nchunks_total);
   const int nk = c_end - c_begin;
@@ -1584,25 +1593,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
 
   __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, g.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, g.dy_bytes, 0x00020000);
-  int i_n, i_ho, i_seg;                             // chunk the next issue() fetches (scalars)
-  {
+  int i_n, i_ho, i_seg;                             // chunk the next issue() fetches (scalars); paired tails: (i_n, i_ho) = row A of the pair, i_seg = index inside the pair
+  if (tail_rem > 0) {
+    i_seg = c_begin % cpp;
+    const int r0 = (c_begin / cpp) * 2;
+    i_ho = r0 % g.Ho;
+    i_n = r0 / g.Ho;
+  } else {
     i_seg = c_begin % nseg;
     const int t = c_begin / nseg;
     i_ho = t % g.Ho;
     i_n = t / g.Ho;
   }
+  auto issue_tail = [&](int slot) {                 // both rows' tails: pixel slots 0..7 <- row A, 8..15 <- row B
+    const int nB = i_ho + 1 < g.Ho ? i_n : i_n + 1, hoB = i_ho + 1 < g.Ho ? i_ho + 1 : 0;
+    const int wo0 = q * 16;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int j = (wave * NA + i) * RPA + a_rsub;
+      const int half = j >> 3, jj = j & 7;
+      const int n_ = half ? nB : i_n, ho_ = half ? hoB : i_ho;
+      const bool ok = a_colok && jj < tail_rem && n_ < g.N;
+      const unsigned off = ok ? (unsigned)((((long)n_ * g.Ho + ho_) * g.Wo + wo0 + jj) * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
+      lds_dma16_buf(off, rs_y, a_dst + slot * STAGE_B + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < NBT / 4 + 1; ++i) {
+      if (i < nb) {
+        const int r = (b_first + i) * RPB + b_rsub;            // staged row 0..19: half = r >= 10
+        const int half = r >= 10 ? 1 : 0, ss = r - 10 * half;
+        const int n_ = half ? nB : i_n, ho_ = half ? hoB : i_ho;
+        const int hi = ho_ - 1 + kh, wi = wo0 - 1 + ss;
+        const bool ok = n_ < g.N && hi >= 0 && hi < g.H && ss < tail_rem + 2 && wi < g.W;
+        lds_dma16_buf(ok ? (unsigned)((((long)n_ * g.H + hi) * g.W + wi) * g.ldx + ci_base + b_col * 4) * 4u : F_OOB, rs_x, b_dst + slot * STAGE_B + i * 1024);
+      }
+    }
+  };
   auto issue = [&](int slot) {
-    const int wo0 = i_seg * 16;
-    const long prow = ((long)i_n * g.Ho + i_ho) * g.Wo + wo0;
+    if (tail_rem > 0) {
+      if (i_seg == 2 * q) {
+        issue_tail(slot);
+        i_seg = 0;
+        i_ho += 2;
+        if (i_ho >= g.Ho) {
+          i_ho -= g.Ho;
+          ++i_n;
+        }
+        return;
+      }
+    }
+    const bool rowB = tail_rem > 0 && i_seg >= q;
+    const int c_n = rowB ? (i_ho + 1 < g.Ho ? i_n : i_n + 1) : i_n;
+    const int c_ho = rowB ? (i_ho + 1 < g.Ho ? i_ho + 1 : 0) : i_ho;
+    const bool rowlive = c_n < g.N;                  // odd row count: the last pair has no row B
+    const int wo0 = (rowB ? i_seg - q : i_seg) * 16;
+    const long prow = ((long)c_n * g.Ho + c_ho) * g.Wo + wo0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int j = (wave * NA + i) * RPA + a_rsub;            // output pixel slot 0..15
-      const unsigned off = (a_colok && wo0 + j < g.Wo) ? (unsigned)((prow + j) * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
+      const unsigned off = (a_colok && rowlive && wo0 + j < g.Wo) ? (unsigned)((prow + j) * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
       lds_dma16_buf(off, rs_y, a_dst + slot * STAGE_B + i * 1024);   // out of range => the hardware writes zeros
     }
-    const int hi = i_ho - 1 + kh;
-    const bool rowok = hi >= 0 && hi < g.H;
-    const long xrow = ((long)i_n * g.H + hi) * g.W;
+    const int hi = c_ho - 1 + kh;
+    const bool rowok = rowlive && hi >= 0 && hi < g.H;
+    const long xrow = ((long)c_n * g.H + hi) * g.W;
 #pragma unroll
     for (int i = 0; i < NBT / 4 + 1; ++i) {
       if (i < nb) {
@@ -1612,7 +1666,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
         lds_dma16_buf(ok ? (unsigned)((xrow + wi) * g.ldx + ci_base + b_col * 4) * 4u : F_OOB, rs_x, b_dst + slot * STAGE_B + i * 1024);
       }
     }
-    if (++i_seg == nseg) {
+    if (tail_rem > 0) {
+      ++i_seg;                                      // the tail chunk (i_seg == 2 q) closes the pair
+    } else if (++i_seg == nseg) {
       i_seg = 0;
       if (++i_ho == g.Ho) {
         i_ho = 0;
@@ -1635,7 +1691,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   // fragment gather offsets inside a stage (bytes): A value j of tile t = raw A[(8 khalf + j)][wm*64 + t*32 + l31];
   // B value j (0..9) = staged row 8 khalf + j, channel wn*32 + l31
   const int a_off = (8 * khalf) * BM * 4 + (wm * 64 + l31) * 4;
-  const int b_off = A_B + (8 * khalf) * CIS * 4 + (wn * NCI + l31) * 4;
+  const int b_off_full = A_B + (8 * khalf) * CIS * 4 + (wn * NCI + l31) * 4;
+  const int b_off_tail = A_B + (10 * khalf) * CIS * 4 + (wn * NCI + l31) * 4;
+  int c_sub = tail_rem > 0 ? c_begin % cpp : 0;     // compute side: position of the current chunk inside its row pair
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int t = 0; t < TM; ++t)
@@ -1656,6 +1714,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
       asm volatile("" ::: "memory");
       if (kc + 2 < nk) issue(nstage);
       const char* sb = lds + stage * STAGE_B;
+      const int b_off = (tail_rem > 0 && c_sub == 2 * q) ? b_off_tail : b_off_full;
+      if (tail_rem > 0) c_sub = c_sub == 2 * q ? 0 : c_sub + 1;
       // A fragments: gather 8 pixels, split
       bf16x8_t ah[TM], al[TM];
 #pragma unroll
@@ -2212,19 +2272,23 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   } while (0)
   if (rowtap) {
     const int nseg = cdiv(g.Wo, 16);
-    const int cps = cdiv(g.N * g.Ho * nseg, p.nsplit);
+    // paired tails (see the kernel): rows of 16 q + rem pixels, 0 < rem <= 8, at least two rows per image
+    const int rem = g.Wo & 15;
+    const int tail_rem = (rem > 0 && rem <= 8 && g.Wo >= 16 && g.Ho >= 2 && g_wgrad_cfg != 9) ? rem : 0;
+    const int nchunks_rt = tail_rem ? ((g.N * g.Ho + 1) / 2) * (2 * (g.Wo / 16) + 1) : g.N * g.Ho * nseg;
+    const int cps = cdiv(nchunks_rt, p.nsplit);
     if (rowtap == 1 && g_conv_math == 2)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
     else if (rowtap == 1)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
     else if (g_conv_math == 2)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
     else
       hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
   } else if (p.bm == 256 && p.bn == 64)
     SRHIP_LW(256, 64, 4, 1);
   else if (p.bm == 64 && p.bn == 256)

@@ -287,10 +287,15 @@ def test_patch_conv_kernel_bit_identical_to_dma_kernel(case):
     assert _rel(out[-2][0], ref) < 1.5e-5
 
 
-@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256)])
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256),
+                                  (1, 64, 23, 23, 128), (3, 64, 23, 22, 128), (2, 128, 19, 40, 64), (1, 64, 2, 24, 256), (3, 128, 5, 17, 128)])
 def test_rowtap_wgrad_against_fp64(case):
     """wgrad_rowtap_kernel (both tile shapes) on ragged widths: rows padded to 16-pixel chunks, 18-pixel staged
-    segments crossing the image border, funnel-shifted kw = 1 fragments; weight and bias gradients vs fp64."""
+    segments crossing the image border, funnel-shifted kw = 1 fragments; weight and bias gradients vs fp64.
+    Widths of 16 q + r with r <= 8 take the paired-tails chunk order (two rows' tails in one chunk): cases with an odd
+    number of rows (23 x 1, 23 x 3, 5 x 3: the last pair has no second row), r = 8 (40 = 2 x 16 + 8: both staged halves
+    full), r = 1 (17) and two-row images (the pair spans the whole image); r > 8 (37 = 2 x 16 + 5 is paired, 20 = 16 + 4
+    is paired, 54 = 3 x 16 + 6 is paired; 16 has no tail and 9 < 16 keeps the one-segment layout)."""
     from sradsgan_amd import ops
     dev = torch.device('cuda:0')
     n, cin, h, w, cout = case
@@ -304,6 +309,15 @@ def test_rowtap_wgrad_against_fp64(case):
         dw, db = ops.conv2d_wgrad_raw(xg, dyg, (cout, cin, 3, 3), 1, 1, True)
     assert _rel(dw, ref) < 1.5e-5
     assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
+    # the one-row-per-chunk-run order (srhip_debug_set(1, 9)) sums the same products in a different split order
+    from sradsgan_amd import _hip
+    _hip.lib().srhip_debug_set(1, 9)
+    try:
+        with ops.conv_math('bf16x3'):
+            dw9, db9 = ops.conv2d_wgrad_raw(xg, dyg, (cout, cin, 3, 3), 1, 1, True)
+    finally:
+        _hip.lib().srhip_debug_set(1, 0)
+    assert _rel(dw9, ref) < 1.5e-5 and _rel(dw9, dw.double()) < 5e-6
 
 
 def test_small_channel_kernels_at_full_image_size():
