@@ -2305,7 +2305,7 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   int rc = check_launch("fast_wgrad");
   if (rc) return rc;
   const long total = (long)cout * g.Ktot + (db ? cout : 0);
-  if (p.nsplit >= 256)
+  if (p.nsplit >= (g_wgrad_cfg == 6 ? 256 : 64))
     hipLaunchKernelGGL(fast_wgrad_reduce_kernel<16>, dim3(cdiv(total, 64)), dim3(1024), 0, st, partial, bias_partial, dw,
                        db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
   else

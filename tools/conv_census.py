@@ -40,7 +40,7 @@ def wrap(name, key_fn):
     setattr(ops, name, f)
 
 
-wrap('conv2d_fwd_raw', lambda x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None:
+wrap("conv2d_fwd_raw", lambda x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None, graddata=False:
      (tuple(x.shape), tuple(w.shape), stride, 'lrelu' if slope is not None else '', 'res' if residual is not None else '', 'scale' if rowscale is not None else ''))
 wrap('conv2d_dgrad_raw', lambda dy, w, x_shape, stride, pad, residual=None, actmask=None, slope=0.0:
      (tuple(dy.shape), tuple(w.shape), stride, 'mask' if actmask is not None else '', 'res' if residual is not None else '', ''))
