@@ -162,8 +162,9 @@ size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int 
   if (fast_wgrad_ok(cin, cout, kh, kw)) return fast_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
   const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
   const long rows = (long)n * ho * wo;
-  return align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad)) +
-         (rows > 0 ? colsum_workspace_bytes(rows, cout) : 0);
+  const size_t colsum_b = rows > 0 ? colsum_workspace_bytes(rows, cout) : 0;
+  const size_t fused_b = legacy_conv2d_wgrad_bias_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
+  return align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad)) + (colsum_b > fused_b ? colsum_b : fused_b);
 }
 
 int srhip_conv2d_wgrad_can_accumulate(int cin, int cout, int kh, int kw) { return fast_wgrad_ok(cin, cout, kh, kw) ? 1 : 0; }
@@ -187,8 +188,10 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, co
     return SRHIP_ERR_WORKSPACE;
   }
   const size_t wbytes = align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad));
-  int rc = legacy_conv2d_wgrad(x, dy, dw, workspace, wbytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy, stream);
-  if (rc || !db) return rc;
+  int bias_done = 0;
+  int rc = legacy_conv2d_wgrad(x, dy, dw, workspace, wbytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy, stream, db,
+                               reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes), &bias_done);
+  if (rc || !db || bias_done) return rc;
   const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
   SRHIP_REQUIRE(cout % 4 == 0 ? cout <= 1024 : cout <= 256, "conv2d_wgrad: too many output channels for the bias sum");
   return colsum_launch(dy, db, static_cast<char*>(workspace) + wbytes, (long)n * ho * wo, cout, ldy, as_stream(stream));

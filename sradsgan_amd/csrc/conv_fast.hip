@@ -1883,6 +1883,49 @@ static int launch_fast(const float* src, const float* wt, const float* bias, con
   return check_launch("fast_conv");
 }
 
+// ================================================================================================ //
+// ONE destination channel on a small grid (the discriminator's head conv 512 -> 1 at 14 x 14: 6272 output pixels, 4608
+// multiply-adds each).  The MFMA kernels pad the channel to a 32-wide tile and have 49 blocks to offer, each walking 288
+// K chunks serially: 230 us for 58 MFLOP, three times per step in the discriminator's serial chain.  Here a wave owns an
+// output pixel: lanes stride the source channels with 16-byte loads (x row and weight row are both contiguous), fp32
+// FMAs, one butterfly reduction.  Exact fp32 in every arithmetic mode.
+// ================================================================================================ //
+__global__ __launch_bounds__(256) void dot_conv_kernel(const float* __restrict__ src, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ dst, FastGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M) return;
+  const int ow = m % g.OW, t = m / g.OW;
+  const int oh = t % g.OH, n = t / g.OH;
+  float acc = 0.f;
+  for (int th = 0; th < g.TH; ++th) {
+    const int sh = oh * g.ss + g.dh0 + th * g.dhs;
+    if (sh < 0 || sh >= g.Hs) continue;
+    for (int tw = 0; tw < g.TW; ++tw) {
+      const int sw = ow * g.ss + g.dw0 + tw * g.dws;
+      if (sw < 0 || sw >= g.Ws) continue;
+      const float* xp = src + ((size_t)(n * g.Hs + sh) * g.Ws + sw) * g.lds;
+      const float* wp = wt + (size_t)((g.kh0 + th * g.khs) * g.KW + (g.kw0 + tw * g.kws)) * g.C;
+      for (int c = lane * 4; c < g.C; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(xp + c);
+        const float4 b = *reinterpret_cast<const float4*>(wp + c);
+        acc = fmaf(a.x, b.x, acc);
+        acc = fmaf(a.y, b.y, acc);
+        acc = fmaf(a.z, b.z, acc);
+        acc = fmaf(a.w, b.w, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    float v = acc;
+    if (g.flags & SRHIP_EPI_BIAS) v += bias[0];
+    if (g.flags & SRHIP_EPI_LRELU) v = v > 0.f ? v : v * g.slope;
+    dst[((size_t)(n * g.Hd + oh * g.dsd + g.ph) * g.Wd + ow * g.dsd + g.pw) * g.ldd] = v;
+  }
+}
+
 // experiment knob (srhip_debug_set(0, cfg)): 0 = heuristic below
 int g_fast_cfg = 0;
 
@@ -1962,6 +2005,12 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     else
       hipLaunchKernelGGL((narrow_conv_kernel<4>), dim3(g.N * th * tw), dim3(256), 0, st, src, wt, bias, dst, g, th, tw, lo_h, lo_w);
     return check_launch("narrow_conv");
+  }
+  // one destination channel, small grid: a wave per output pixel (cfg 22 turns it off with the other VALU kernel)
+  if (g.K == 1 && g.C % 4 == 0 && g.lds % 4 == 0 && (((uintptr_t)src | (uintptr_t)wt) & 15) == 0 && g.M < 65536 && g_fast_cfg != 20 &&
+      g_fast_cfg != 22 && !(g.flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU | SRHIP_EPI_GRADDATA)) && !g.accumulate) {
+    hipLaunchKernelGGL(dot_conv_kernel, dim3(cdiv(g.M, 4)), dim3(256), 0, st, src, wt, bias, dst, g);
+    return check_launch("dot_conv");
   }
   // 16-bit product arithmetic (see mma16): 0 split-bf16 (three products), 1 one bf16 product (SRHIP_MATH_HALF on gradient
   // data: every dgrad, and forward calls flagged GRADDATA), 2 one fp16 product (SRHIP_MATH_HALF on activations)

@@ -485,8 +485,11 @@ __global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restri
 // three input rows (zero halo) are staged in LDS; per pixel pair a wave issues two coalesced dy loads (A operand:
 // lane = channel, half-wave = pixel), one LDS gather (B operand: lane = column (tap, ci), half-wave = pixel) and two
 // MFMAs.  The four waves take interleaved pixel pairs and are summed through LDS at the end.
+// bias_partial != nullptr: the bias gradient (column sums of dy) comes out of the same pass -- every dy value is in a
+// register here anyway; the separate colsum pass re-read the 382 MB of the 216 x 216 x 64 gradient (123 us, 7 per step).
 __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ partial, int N, int H, int W, int cin,
+                                                              float* __restrict__ partial, float* __restrict__ bias_partial,
+                                                              int N, int H, int W, int cin,
                                                               int cout, int ldx, int ldy, int rows_per_split) {
   extern __shared__ float xs[];                      // [3][W + 2][cin] (zero outside the image), then the reduce area
   const int tid = threadIdx.x, lane = tid & 63;
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __rest
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  float bs0 = 0.f, bs1 = 0.f;                        // this lane's share of the bias gradient of channels co0 + l31 (+ 32)
   const int r_begin = blockIdx.x * rows_per_split, r_end = min(r_begin + rows_per_split, N * H);
   for (int r = r_begin; r < r_end; ++r) {
     const int n = r / H, oh = r - n * H;
@@ -524,6 +528,8 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __rest
       const float d0 = (pok && c0ok) ? drow[(size_t)p * ldy] : 0.f;
       const float d1 = (pok && c1ok) ? drow[(size_t)p * ldy + 32] : 0.f;
       const float b = (pok && koff >= 0) ? xs[p * cin + koff] : 0.f;
+      bs0 += d0;
+      bs1 += d1;
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, acc1, 0, 0, 0);
     }
@@ -543,6 +549,18 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __rest
     if (k < ktot && co0 + co < cout)
       partial[((size_t)blockIdx.x * cout + co0 + co) * ktot + k] =
           (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+  }
+  if (bias_partial != nullptr) {                     // 8 contributions per channel (4 waves x 2 pixel parities), fixed order
+    __syncthreads();
+    red[(wave * 2 + half) * 64 + l31] = bs0;
+    red[(wave * 2 + half) * 64 + 32 + l31] = bs1;
+    __syncthreads();
+    if (tid < 64 && co0 + tid < cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += red[j * 64 + tid];
+      bias_partial[(size_t)blockIdx.x * cout + co0 + tid] = s;
+    }
   }
 }
 
@@ -742,9 +760,19 @@ size_t legacy_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int
   return (size_t)p.nsplit * cout * kh * kw * cin * sizeof(float);
 }
 
+size_t legacy_conv2d_wgrad_bias_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+  const long M = (long)n * ho * wo;
+  if (M <= 0) return 0;
+  return (size_t)plan_wgrad((int)M, cout, kh * kw * cin).nsplit * cout * sizeof(float);
+}
+
+// db / bias_ws / bias_done: kernels that see every dy value anyway also produce the bias gradient (bias_ws >=
+// legacy_conv2d_wgrad_bias_workspace bytes) and set *bias_done; otherwise the caller runs the column-sum pass.
 int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
                        int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
-                       void* stream) {
+                       void* stream, float* db, float* bias_ws, int* bias_done) {
+  if (bias_done) *bias_done = 0;
   SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
   SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                 "conv2d_wgrad: bad geometry");
@@ -773,13 +801,18 @@ int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* worksp
     int ns = p.nsplit < rows ? p.nsplit : rows;                       // splits the workspace was sized for
     const int rps = cdiv(rows, ns);
     ns = cdiv(rows, rps);
+    const bool fuse_bias = db != nullptr && bias_ws != nullptr && bias_done != nullptr;
     hipLaunchKernelGGL(wgrad_smallcin_kernel, dim3(ns, cdiv(cout, 64)), dim3(256), (size_t)32 * 1024, st,
-                       x, dy, partial, n, h, w, cin, cout, ldx, ldy, rps);
+                       x, dy, partial, fuse_bias ? bias_ws : nullptr, n, h, w, cin, cout, ldx, ldy, rps);
     int rc0 = check_launch("wgrad_smallcin");
     if (rc0) return rc0;
     long total0 = (long)cout * g.Ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total0, 16)), dim3(256), 0, st, partial, dw, ns, cout, cin, kh * kw,
                        g.Ktot);
+    if (fuse_bias) {                                  // bias_ws[split][cout] -> db[cout]: the same reduce with a 1-column matrix
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, st, bias_ws, db, ns, cout, 1, 1, 1);
+      *bias_done = 1;
+    }
     return check_launch("wgrad_reduce");
   }
   const bool va = (cout % 4 == 0) && (ldy % 4 == 0);

@@ -13,9 +13,10 @@ int legacy_conv2d_fwd(const float* x, const float* packed, const float* bias, co
 int legacy_conv2d_dgrad(const float* dy, const float* packed, float* dx, int n, int h, int w, int cin, int cout,
                         int kh, int kw, int stride, int pad, int ldy, int ldx, int accumulate, void* stream);
 size_t legacy_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
+size_t legacy_conv2d_wgrad_bias_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
 int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
                         int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
-                        void* stream);
+                        void* stream, float* db = nullptr, float* bias_ws = nullptr, int* bias_done = nullptr);
 
 // ---- fast path (conv_fast.hip): source channels % 16 == 0, <= 32 taps ------------------------- //
 // fprop/dgrad eligibility depends only on the conv's static shape, so the packed-weight layout

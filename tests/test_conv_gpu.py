@@ -349,3 +349,32 @@ def test_small_channel_kernels_at_full_image_size():
     refh = F.leaky_relu(F.conv2d(x3.double(), w0.double(), b0.double(), padding=1), 0.2)
     goth = ops.conv2d_fwd_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(w0.to(dev)), b0.to(dev), 1, 1, 0.2)
     assert _rel(goth, refh) < 5e-6
+
+
+@pytest.mark.parametrize('case', [(2, 512, 14, 14, 3, 1), (3, 64, 9, 11, 3, 1), (2, 260, 7, 5, 1, 0), (1, 128, 20, 20, 3, 1)])
+def test_single_destination_channel_small_grid(case):
+    """dot_conv_kernel (one wave per output pixel; the discriminator's head conv 512 -> 1 at 14 x 14): forward with bias /
+    LeakyReLU against fp64, channel counts that are not a multiple of the 256-channel lane stride, and the MFMA path it
+    replaces (srhip_debug_set(0, 22)) as a cross-check."""
+    import torch.nn.functional as F
+    from sradsgan_amd import ops, _hip
+    dev = torch.device('cuda:0')
+    n, cin, h, w, k, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.nn.Parameter((torch.randn(1, cin, k, k, generator=g) * 0.05).to(dev))
+    b = torch.randn(1, generator=g)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    for bias, slope in ((None, None), (b, None), (b, 0.2)):
+        ref = F.conv2d(x.double(), wt.detach().cpu().double(), None if bias is None else bias.double(), padding=pad)
+        if slope is not None:
+            ref = F.leaky_relu(ref, slope)
+        bg = None if bias is None else bias.to(dev)
+        y = ops.conv2d_fwd_raw(xg, wt, bg, 1, pad, slope)
+        assert _rel(y, ref) < 5e-6, (bias is not None, slope)
+        _hip.lib().srhip_debug_set(0, 22)
+        try:
+            y22 = ops.conv2d_fwd_raw(xg, wt, bg, 1, pad, slope)
+        finally:
+            _hip.lib().srhip_debug_set(0, 0)
+        assert _rel(y22, ref) < 2e-5

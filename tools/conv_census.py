@@ -51,7 +51,7 @@ torch.cuda.synchronize()
 rows = sorted(stats.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for _, v in rows)
 print('total conv time (standalone, incl. ~10 us launch+sync each): %.1f ms over %d calls' % (tot / 1e3, sum(v[0] for _, v in rows)))
-for k, (n, t) in rows[:45]:
+for k, (n, t) in rows[:int(__import__("os").environ.get("TOP", "45"))]:
     kind, xs, ws, stride = k[0], k[1], k[2], k[3]
     cout, cin, kh, kw = ws
     n_, _, h, w = xs
