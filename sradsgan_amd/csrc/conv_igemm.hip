@@ -564,6 +564,96 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __rest
   }
 }
 
+// ---- weight gradient of 3x3 stride-1 pad-1 convs with <= 4 OUTPUT channels at full image size (generator tail conv 64 -> 3
+// at 216 x 216: 1.5 M pixels) ---- //
+// dW[co][tap][ci] = sum over pixels of dy[p][co] * x[p + tap][ci]: 1728 outputs, each a reduction over every pixel, 5 GFLOP
+// in all.  The generic kernel pads the 3 channels to a 32-wide MFMA tile and spends 1.1 ms on gather bookkeeping; an
+// MFMA formulation wastes 10x the arithmetic on that padding.  Here a block of 9 x 64 threads owns one 64-channel slice:
+// thread = (tap, ci) keeps its <= 4 sums in registers and walks 16 x 16 pixel patches; the 18 x 18 x 64 halo of a patch and
+// its 256 dy vectors are staged in LDS (zero outside the image), so the inner step is one conflict-free LDS read of x,
+// one broadcast read of dy and <= 4 FMAs.  One partial [co][tap][ci] tile per block, summed by wgrad_reduce_kernel.
+template <int ND>
+__global__ __launch_bounds__(576) void wgrad_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partial, int N, int H, int W, int cin,
+                                                            int ldx, int ldy, int tiles_h, int tiles_w) {
+  constexpr int PW = 16, PH = 16, PWP = PW + 2, NPX = (PH + 2) * PWP;   // 324 halo pixels
+  constexpr int NLD = (NPX * 16 + 575) / 576;        // float4 loads per thread and patch (9)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ float xs[];                      // [324][64], then the patch's 256 dy vectors (float4, zero outside the image)
+  float4* dys = reinterpret_cast<float4*>(xs + NPX * 64);
+  const int tid = threadIdx.x;
+  const int tap = tid >> 6, ci = tid & 63;
+  const int kh = tap / 3, kw = tap - kh * 3;
+  const int ci0 = blockIdx.y * 64;
+  const int npatch = N * tiles_h * tiles_w;
+  const int tpi = tiles_h * tiles_w;
+  f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+  float4 stage[NLD];
+  float4 dstage = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int pid) {                         // the halo of patch pid and its dy vectors: global -> registers
+    const int n = pid / tpi, prem = pid - n * tpi;
+    const int ty = prem / tiles_w, tx = prem - ty * tiles_w;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * 576;
+      const int px = e >> 4, q = e & 15;
+      const int pi = px / PWP, pj = px - pi * PWP;
+      const int ih = ty * PH - 1 + pi, iw = tx * PW - 1 + pj;
+      stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NPX * 16 && ih >= 0 && ih < H && iw >= 0 && iw < W)
+        stage[i] = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + ih) * W + iw) * ldx + ci0 + q * 4);
+    }
+    dstage = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < PH * PW) {
+      const int oh = ty * PH + (tid >> 4), ow = tx * PW + (tid & 15);
+      if (oh < H && ow < W) {
+        const float* dp = dy + ((size_t)(n * H + oh) * W + ow) * ldy;
+        dstage.x = dp[0];
+        if (ND > 1) dstage.y = dp[1];
+        if (ND > 2) dstage.z = dp[2];
+        if (ND > 3) dstage.w = dp[3];
+      }
+    }
+  };
+  int pid = blockIdx.x;
+  if (pid < npatch) fetch(pid);
+  const float* xb = xs + (kh * PWP + kw) * 64 + ci;
+  for (; pid < npatch; pid += gridDim.x) {
+    __syncthreads();                                  // the previous patch is consumed
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * 576;
+      if (e < NPX * 16) *reinterpret_cast<float4*>(xs + (e >> 4) * 64 + (e & 15) * 4) = stage[i];
+    }
+    if (tid < PH * PW) dys[tid] = dstage;
+    __syncthreads();
+    if (pid + (int)gridDim.x < npatch) fetch(pid + gridDim.x);   // next patch's loads fly under this patch's arithmetic
+#pragma unroll 2
+    for (int py = 0; py < PH; ++py) {
+      float v[PW];
+      float4 d[PW];
+#pragma unroll
+      for (int px = 0; px < PW; ++px) {
+        v[px] = xb[(py * PWP + px) * 64];
+        d[px] = dys[py * PW + px];                   // uniform address: one broadcast read
+      }
+#pragma unroll
+      for (int px = 0; px < PW; ++px) {
+        const f32x2 vv = {v[px], v[px]};
+        const f32x2 d01 = {d[px].x, d[px].y}, d23 = {d[px].z, d[px].w};
+        acc01 = __builtin_elementwise_fma(vv, d01, acc01);
+        if (ND > 2) acc23 = __builtin_elementwise_fma(vv, d23, acc23);
+      }
+    }
+  }
+  const int ktot = 9 * cin;
+  float* o = partial + (size_t)blockIdx.x * ND * ktot + tap * cin + ci0 + ci;
+  o[0] = acc01.x;
+  if (ND > 1) o[ktot] = acc01.y;
+  if (ND > 2) o[2 * ktot] = acc23.x;
+  if (ND > 3) o[3 * ktot] = acc23.y;
+}
+
 // partial[s][co][(kh,kw,ci)] --sum over s--> dw[co][ci][kh][kw]
 // 16 outputs per block x 16 split lanes (the small-channel convs have few outputs and ~1000 splits: one thread per
 // output walked them serially, 235 us for 1728 outputs)
@@ -813,6 +903,33 @@ int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* worksp
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cout, 16)), dim3(256), 0, st, bias_ws, db, ns, cout, 1, 1, 1);
       *bias_done = 1;
     }
+    return check_launch("wgrad_reduce");
+  }
+  if (cout <= 4 && cin % 64 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && kh == 3 && kw == 3 && stride == 1 && pad == 1 &&
+      g.M >= 65536 && p.nsplit >= 64) {
+    const int th = cdiv(h, 16), tw = cdiv(w, 16);
+    const int ns = p.nsplit < 256 ? p.nsplit : 256;                   // one 576-thread block per CU; the workspace holds p.nsplit tiles
+    const size_t lds_bytes = (size_t)(18 * 18 * 64 + 256 * 4) * sizeof(float);
+#define SRHIP_WN(ND_)                                                                                                    \
+  do {                                                                                                                   \
+    static bool attr_set = false;                                                                                        \
+    if (!attr_set) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_narrow_kernel<ND_>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                             \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(wgrad_narrow_kernel<ND_>, dim3(ns, cin / 64), dim3(576), lds_bytes, st, x, dy, partial, n, h, w,  \
+                       cin, ldx, ldy, th, tw);                                                                           \
+  } while (0)
+    if (cout == 1) SRHIP_WN(1);
+    else if (cout == 2) SRHIP_WN(2);
+    else if (cout == 3) SRHIP_WN(3);
+    else SRHIP_WN(4);
+#undef SRHIP_WN
+    int rc1 = check_launch("wgrad_narrow");
+    if (rc1) return rc1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)cout * g.Ktot, 16)), dim3(256), 0, st, partial, dw, ns, cout, cin,
+                       kh * kw, g.Ktot);
     return check_launch("wgrad_reduce");
   }
   const bool va = (cout % 4 == 0) && (ldy % 4 == 0);

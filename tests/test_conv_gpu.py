@@ -345,6 +345,16 @@ def test_small_channel_kernels_at_full_image_size():
     dw, db = ops.conv2d_wgrad_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), dyg, (64, 3, 3, 3), 1, 1, True)
     assert _rel(dw, refw) < 5e-6
     assert _rel(db, dy.double().sum((0, 2, 3))) < 5e-6
+    # weight + bias gradient of the 64 -> 3 tail conv (wgrad_narrow_kernel: thread = (tap, ci), 16 x 16 pixel patches), and of a
+    # 128 -> 4 conv (two channel slices, four sums per thread)
+    for cin_, cout_ in ((64, 3), (128, 4), (64, 1)):
+        xs_ = torch.randn(n, cin_, h, w, generator=g)
+        dys_ = torch.randn(n, cout_, h, w, generator=g)
+        refw_ = torch.nn.grad.conv2d_weight(xs_.double(), (cout_, cin_, 3, 3), dys_.double(), padding=1)
+        dw_, db_ = ops.conv2d_wgrad_raw(xs_.to(dev).contiguous(memory_format=torch.channels_last),
+                                        dys_.to(dev).contiguous(memory_format=torch.channels_last), (cout_, cin_, 3, 3), 1, 1, True)
+        assert _rel(dw_, refw_) < 5e-6, (cin_, cout_)
+        assert _rel(db_, dys_.double().sum((0, 2, 3))) < 5e-6
     b0 = torch.randn(64, generator=g)                                  # head conv forward, bias + LeakyReLU
     refh = F.leaky_relu(F.conv2d(x3.double(), w0.double(), b0.double(), padding=1), 0.2)
     goth = ops.conv2d_fwd_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(w0.to(dev)), b0.to(dev), 1, 1, 0.2)
