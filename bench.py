@@ -81,6 +81,9 @@ def parse():
     ap.add_argument('--scales', default='2,3,4,8,9', help='--workload chain: comma-separated scale factors')
     ap.add_argument('--roofline-only', action='store_true',
                     help='run only the dominant-kernel measurement (profiles/: rocprofv3 --kernel-trace --stats of this)')
+    ap.add_argument('--no-sustained', action='store_true',
+                    help='skip the 1.2 s power / clock sampling loops of the roofline kernels (profiler runs: keeps the per-dispatch '
+                         'statistics to the timed launches)')
     ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
     return ap.parse_args()
 
@@ -208,7 +211,7 @@ def _time_isolated(fn, iters=20):
     return tot / iters
 
 
-def time_dominant_kernel(device, batch):
+def time_dominant_kernel(device, batch, sustained=True):
     """HIP-event timing, on the stream they are launched on, of the two kernels that dominate the step at the
     bench shape [batch,64,54,54] (36 RAB blocks): the conv fprop/dgrad kernel on RAB conv1 (3x3, 64->256, +bias
     +LeakyReLU) -> 'roofline', and the wgrad kernel on the same conv -> second return value."""
@@ -252,6 +255,10 @@ def time_dominant_kernel(device, batch):
                'dtype_peak': peak_name}
         # the same launch looped for ~1.2 s with the board's power and shader clock sampled: `peak` assumes the nominal
         # clock, the kernel runs at whatever clock the 1400 W cap leaves (extra keys, not part of frac)
+        if not sustained:                                   # profiler runs: keep the per-dispatch statistics to the timed launches
+            rec['power'] = None
+            out.append(rec)
+            continue
         with PowerSampler(device.index or 0) as ps:
             t_end = time.perf_counter() + 1.2
             n = 0
@@ -583,7 +590,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     if args.roofline_only:
-        r0, r1 = time_dominant_kernel(device, args.batch)
+        r0, r1 = time_dominant_kernel(device, args.batch, not args.no_sustained)
         print(json.dumps({'roofline': r0, 'roofline_wgrad': r1}), flush=True)
         return
     if args.workload == 'infer':
@@ -693,7 +700,7 @@ def main():
             line['exchange'] = 'srhip_dp_allreduce_bucket on a dedicated HIP stream, G arena under the D step'
         if alt is not None:
             line['exact_fp32_mode'] = alt
-        line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B)
+        line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B, not args.no_sustained)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
     if world > 1 or force_dist:

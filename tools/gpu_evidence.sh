@@ -14,7 +14,7 @@ timeout 900 python bench.py --workload chain --conv-math bf16x3 2>&1 | tail -1 >
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $E/bench_n1_rccl_single_rank.json; cut -c1-200 $E/bench_n1_rccl_single_rank.json
 timeout 600 python bench.py --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_again.json; cut -c1-200 $E/bench_n1_again.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --no-sustained --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
 cd $R
 f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 70 > $E/step_kernel_stats.txt; head -14 $E/step_kernel_stats.txt
 bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -12 $E/roofline2.log
