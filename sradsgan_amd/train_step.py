@@ -216,12 +216,14 @@ class TrainStep:
             main = torch.cuda.current_stream()
             dside = self._d_stream if self._d_stream is not None else side   # third stream: the D passes beside G's dgrads (main) and the wgrads (side)
             self._mark('fwd done (VGG, D(gen), losses)')
-            late = os.environ.get('SRHIP_D_FWD_FIRST', '0') != '1'          # A/B knob: '1' restores the old enqueue order
+            late = os.environ.get('SRHIP_D_LATE', '0') == '1'               # A/B knob, off by default
             if late:
-                # The HOST enqueues the generator's backward first and the D passes second; the D stream waits only for the
-                # forward (event), so its kernels still run beside the generator's backward.  With a slow host (under a
-                # profiler) the ~440 launches of the D passes enqueued first left the main stream dry for 6.6 ms per step;
-                # at full host speed the two orders time the same (tools/step_timeline.py).
+                # Alternative HOST order: the generator's backward first, the D passes second (the D stream waits only for a
+                # forward-done event, so its kernels still run beside the generator's backward).  It removes a 6.6 ms dry
+                # spell of the main stream when the host is slow (under rocprofv3) and times the same at full host speed --
+                # but with the gradient exchange active it is 19 % SLOWER (74.0 vs 62.8 ms, single-rank communicator):
+                # the RCCL enqueue in _exchange_start('G') holds the host until the generator's backward has run, and in
+                # this order the D passes are not enqueued yet at that point.  Hence the D passes go first.
                 fwd_done = torch.cuda.Event()
                 fwd_done.record(main)
                 with ops.backward_scope(skip_params=d_params):    # no discriminator wgrads in the G step (:857 -> :865)
