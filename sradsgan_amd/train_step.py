@@ -36,6 +36,8 @@ def _ptr(t):
 
 
 class TrainStep:
+    _timeline_on = False        # SRHIP_STEP_TIMELINE=1 (set per instance in __init__)
+
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
                  grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True, overlap_d_step=True):
