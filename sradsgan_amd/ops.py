@@ -344,16 +344,30 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
             if t is not None:
                 t.record_stream(side)
         return None, None
-    dw, db = conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
-    if gw is not None and (db is None or gb is not None):
-        # Shapes the accumulating kernel does not take (the 3- and 2-channel convs): add in program order here rather than
-        # through autograd's AccumulateGrad, whose order among several contributions to one parameter follows per-thread
-        # node counters (the first step of a process differs from later ones by an ulp, tests/test_graph_gpu.py).
-        gw.add_(dw)
-        if db is not None:
-            gb.add_(db)
+    if gw is not None and (not want_b or gb is not None):
+        # Shapes the accumulating kernel does not take (the 3- and 2-channel convs, the 64 -> 3 tail conv): add in program order
+        # here rather than through autograd's AccumulateGrad, whose order among several contributions to one parameter
+        # follows per-thread node counters (tests/test_graph_gpu.py) -- and, like the other weight gradients, on the side
+        # stream: the 3 -> 64 head convs' gradients (0.2 - 0.3 ms each at 216 x 216) sat in the discriminator's serial chain
+        side = _state.wgrad_stream
+        if side is None:
+            dw, db = conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
+            gw.add_(dw)
+            if db is not None:
+                gb.add_(db)
+            return None, None
+        x, dy = nhwc(x), nhwc(dy)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dw, db = conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
+            gw.add_(dw)
+            if db is not None:
+                gb.add_(db)
+        for t in (x, dy, xrowscale, xchanscale):
+            if t is not None:
+                t.record_stream(side)
         return None, None
-    return dw, db
+    return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
 
 
 def colsum_raw(dy):

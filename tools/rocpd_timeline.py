@@ -51,6 +51,23 @@ def main(path, which=-2):
             others[q] = busy / d
         print('  gap %7.1f us at +%6.2f ms  after %-45s before %-45s other streams busy %s' % (
             d / 1e3, (a - t0) / 1e6, short(pn), short(nn), {q: round(v, 2) for q, v in others.items()}))
+    # the tail of the step: everything after the last weight-gradient kernel of the generator's backward is the discriminator's backward
+    import os
+    tail_ms = float(os.environ.get('TAIL_MS', '16'))
+    w0 = t1 - int(tail_ms * 1e6)
+    agg = {}
+    busy = {}
+    for n, s_, e_, q in step:
+        if e_ <= w0:
+            continue
+        d = e_ - max(s_, w0)
+        a = agg.setdefault((q, short(n)), [0, 0])
+        a[0] += 1
+        a[1] += d
+        busy[q] = busy.get(q, 0) + d
+    print('last %.0f ms of the step: busy per stream %s' % (tail_ms, {q: round(v / 1e6, 2) for q, v in sorted(busy.items())}))
+    for (q, n), (cnt, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print('   stream %s  %-62s calls %4d  %7.2f ms  avg %7.1f us' % (q, n, cnt, d / 1e6, d / cnt / 1e3))
     # concurrency histogram
     ev = []
     for n, s, e, q in step:
