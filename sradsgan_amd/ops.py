@@ -10,6 +10,7 @@ No CPU path exists: a CPU tensor raises.
 """
 import contextlib
 import ctypes
+import os
 import threading
 import weakref
 
@@ -157,7 +158,7 @@ class _PackRegistry:
     bump_weight_epoch) instead of ~280 tiny pack launches scattered through the next iteration."""
 
     def __init__(self):
-        self.entries = []        # [weakref(w), mode, packed, data_ptr, version]
+        self.entries = []        # [weakref(w), mode, packed, data_ptr, version, pack event or None, packing stream, streams that waited]
         self.table = None
         self.dirty = True
 
@@ -195,12 +196,42 @@ def repack_all():
     _hip.check(lib.srhip_pack_weights_batched(_p(reg.table), len(reg.entries), _stream()), 'pack_weights_batched')
     for ent, w in zip(reg.entries, live):
         ent[4] = w._version
+        ent[5] = None            # re-packed here, at the step boundary every other stream synchronises with (see _pack_fence)
 
 
 def bump_weight_epoch():
     """Called by the fused optimiser (it updates parameters through raw pointers, which does not bump
     tensor._version): re-packs every registered conv weight in one launch."""
     repack_all()
+
+
+_NO_PACK_FENCE = os.environ.get('SRHIP_NO_PACK_FENCE') == '1'     # debug: reproduces the unordered first step
+
+
+def _pack_fence(ent):
+    """A packed image is written by a kernel on the stream that first needed it (lazily, in the first step: the weight-
+    gradient stream packs VGG's weights for the real batch, the D stream packs the discriminator's data-gradient images
+    for the penalty's first-order backward) and read by every stream afterwards.  Nothing else orders those reads behind
+    the pack kernel: in the first step of a model the main stream could run D(gen)'s data gradients on images the D stream
+    had not packed yet -- zeros on fresh memory (a silently wrong first step), NaNs on recycled memory
+    (tools/check_nan.py).  The entry carries the pack's event; a stream waits for it once."""
+    ev = ent[5]
+    if ev is None or _NO_PACK_FENCE:
+        return
+    cs = torch.cuda.current_stream()
+    sid = cs.cuda_stream
+    if sid == ent[6] or sid in ent[7]:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                   # a capture starts long after the eager warm-up iteration that packed
+    cs.wait_event(ev)
+    ent[7].add(sid)
+
+
+def _pack_event(ent):
+    ev = torch.cuda.Event()
+    ev.record()
+    ent[5], ent[6], ent[7] = ev, torch.cuda.current_stream().cuda_stream, set()
 
 
 def mark_static(module):
@@ -225,7 +256,9 @@ def packed_weight(w, mode):
     if ent is None or ent[3] != w.data_ptr():
         packed = torch.empty(lib.srhip_packed_elems(cout, cin, kh, kw, mode), device=w.device, dtype=torch.float32)
         _pack_now(w, mode, packed)
-        new = [weakref.ref(w), mode, packed, w.data_ptr(), w._version]
+        new = [weakref.ref(w), mode, packed, w.data_ptr(), w._version, None, 0, set()]
+        if w.is_cuda and not torch.cuda.is_current_stream_capturing():
+            _pack_event(new)
         if ent is not None and ent in _registry.entries:
             _registry.entries.remove(ent)
         slots[mode] = new
@@ -234,8 +267,13 @@ def packed_weight(w, mode):
             _registry.dirty = True
         return packed
     if ent[4] != w._version:                       # changed by a torch op (load_state_dict, torch optimiser, ...)
+        _pack_fence(ent)                           # (write after the reads other streams may still have in flight is the caller's order)
         _pack_now(w, mode, ent[2])
         ent[4] = w._version
+        if not torch.cuda.is_current_stream_capturing():
+            _pack_event(ent)
+    else:
+        _pack_fence(ent)
     return ent[2]
 
 

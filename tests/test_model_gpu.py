@@ -348,3 +348,36 @@ def test_training_step_is_deterministic():
     for group in (1, 2):
         for a, b in zip(results[0][group], results[1][group]):
             assert torch.equal(a, b)
+
+
+def test_first_step_of_a_model_does_not_depend_on_allocator_history():
+    """The first step of a model packs weights lazily on whichever stream needs them first (VGG's for the real batch on the
+    weight-gradient stream, the discriminator's data-gradient images on the D stream); every other stream must wait for
+    those pack kernels (ops._pack_fence).  Without the fence the main stream ran D(gen)'s data gradients on unpacked
+    images: zeros on fresh memory -- a silently wrong first step --, NaNs on recycled memory.  Two identical models in one
+    process, the second on recycled (NaN-poisoned) memory, at the bench configuration: identical, finite first-step
+    gradients and scalars."""
+    from sradsgan_amd.train_step import TrainStep
+    B = 32
+    lr = O.det_fill('first.lr', (B, 3, 54, 54), 0.5, 0.5).to(DEV)
+    hr = O.det_fill('first.hr', (B, 3, 216, 216), 0.5, 0.5).to(DEV)
+    al = O.det_fill('first.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
+
+    def run():
+        (hg, hd, hf), _ = build_pair(12, 3, 4, DEV)
+        step = TrainStep(hg, hd, hf)
+        out = step(lr, hr, al)
+        torch.cuda.synchronize()
+        grads = [p.grad.detach().clone() for p in list(hg.parameters()) + list(hd.parameters())]
+        return torch.stack([out[k].double() for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')]).cpu(), grads
+
+    s1, g1 = run()
+    keep = [torch.full(((256 << 20) // 4,), float('nan'), device=DEV) for _ in range(24)] + \
+           [torch.full(((2 << 20) // 4,), float('nan'), device=DEV) for _ in range(64)]
+    torch.cuda.synchronize()
+    del keep
+    s2, g2 = run()
+    assert torch.isfinite(s1).all() and torch.isfinite(s2).all()
+    assert all(bool(torch.isfinite(g).all()) for g in g1 + g2)
+    assert torch.equal(s1, s2)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
