@@ -350,21 +350,22 @@ def test_training_step_is_deterministic():
             assert torch.equal(a, b)
 
 
-def test_first_step_of_a_model_does_not_depend_on_allocator_history():
+@pytest.mark.parametrize('scale,batch,blocks,groups', [(4, 32, 12, 3), (2, 2, 2, 2), (3, 4, 2, 1), (8, 8, 2, 2), (9, 6, 2, 1)])
+def test_first_step_of_a_model_does_not_depend_on_allocator_history(scale, batch, blocks, groups):
     """The first step of a model packs weights lazily on whichever stream needs them first (VGG's for the real batch on the
     weight-gradient stream, the discriminator's data-gradient images on the D stream); every other stream must wait for
     those pack kernels (ops._pack_fence).  Without the fence the main stream ran D(gen)'s data gradients on unpacked
     images: zeros on fresh memory -- a silently wrong first step --, NaNs on recycled memory.  Two identical models in one
-    process, the second on recycled (NaN-poisoned) memory, at the bench configuration: identical, finite first-step
-    gradients and scalars."""
+    process, the second on recycled (NaN-poisoned) memory, at the bench configuration and at the other scales' real tile
+    sizes: identical, finite first-step gradients and scalars."""
     from sradsgan_amd.train_step import TrainStep
-    B = 32
-    lr = O.det_fill('first.lr', (B, 3, 54, 54), 0.5, 0.5).to(DEV)
-    hr = O.det_fill('first.hr', (B, 3, 216, 216), 0.5, 0.5).to(DEV)
+    B, side = batch, 216 // scale
+    lr = O.det_fill('first.lr', (B, 3, side, side), 0.5, 0.5).to(DEV)
+    hr = O.det_fill('first.hr', (B, 3, side * scale, side * scale), 0.5, 0.5).to(DEV)
     al = O.det_fill('first.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
 
     def run():
-        (hg, hd, hf), _ = build_pair(12, 3, 4, DEV)
+        (hg, hd, hf), _ = build_pair(blocks, groups, scale, DEV)
         step = TrainStep(hg, hd, hf)
         out = step(lr, hr, al)
         torch.cuda.synchronize()
