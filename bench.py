@@ -414,7 +414,8 @@ def run_chain(args, device):
                            'peak_mem_gb': round(peak0 / 2 ** 30, 1)}
         tot_t, tot_img = tot_t + dt, tot_img + B * args.steps
         del step, G, D, Fx, hr, lr
-        torch.cuda.empty_cache()
+        if os.environ.get('BENCH_CHAIN_EMPTY_CACHE', '0') == '1':
+            torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
     math = ops.get_conv_math()
     print(json.dumps({'metric': 'chain-training images/sec over the scale sweep (HR 216x216 tiles)', 'value': round(tot_img / tot_t, 2),

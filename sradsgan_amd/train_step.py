@@ -35,12 +35,28 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    """The two side streams of the step, ONE pair per process and device, created when the first TrainStep is built.  torch
+    hands out its pool streams round robin and ROCm binds a stream to a hardware queue when it is created: a second model
+    in the same process (chain training, a sweep) used to get two fresh pool streams created late, and its step ran up to
+    34 % slower (x3 after x2: 112 instead of 84 ms) -- the same pair for every model keeps the queue assignment of the
+    first."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _SIDE_STREAMS[key]
+
+
 class TrainStep:
     _timeline_on = False        # SRHIP_STEP_TIMELINE=1 (set per instance in __init__)
 
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
-                 grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True, overlap_d_step=True):
+                 grad_sync=None, use_graph=False, reuse_d_fake=True, overlap_wgrad=True, overlap_d_step=True,
+                 wgrad_stream=None, d_stream=None):
         self.G, self.D, self.F = generator, discriminator, feature_extractor
         self.weight_content, self.weight_gan = weight_content, weight_gan
         self.lambda_gp, self.clip_value, self.use_gp = lambda_gp, clip_value, use_gp
@@ -56,9 +72,10 @@ class TrainStep:
             # D's parameters are used on both streams by design; the engine orders their AccumulateGrad nodes itself
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = self.arena_G.flat_p.device
-        self._wgrad_stream = torch.cuda.Stream(device=dev) if (overlap_wgrad and dev.type == 'cuda') else None
-        d_prio = -1 if os.environ.get('SRHIP_D_PRIO') == '1' else 0     # experiment knob: discriminator stream at high priority
-        self._d_stream = torch.cuda.Stream(device=dev, priority=d_prio) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
+        shared = _side_streams(dev) if (overlap_wgrad and dev.type == 'cuda') else (None, None)
+        self._wgrad_stream = (wgrad_stream or shared[0]) if (overlap_wgrad and dev.type == 'cuda') else None
+        d_default = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('SRHIP_D_PRIO') == '1' else shared[1]   # knob: D stream at high priority
+        self._d_stream = (d_stream or d_default) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         self._graph = None
         self._capturing = False
