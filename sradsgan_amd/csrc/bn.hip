@@ -68,16 +68,20 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
   }
 }
 
+// Stage-2 kernels: 16 channels x BN_SUBS lanes per block walk the <= 1024 stage-1 partials.  With 16 lanes a thread
+// made 64 dependent trips (22 - 54 us per launch for a few KB of work, ~40 launches per step in the discriminator's serial chain).
+constexpr int BN_SUBS = 64;
+
 // stage 2 (forward): per channel mean / invstd, running statistics
 __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
                                 float* __restrict__ invstd, float* __restrict__ running_mean,
                                 float* __restrict__ running_var, int nblk, int c, long rows, float eps,
                                 float momentum) {
-  __shared__ float r0[256], r1[256];
-  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;      // 16 columns x 16 slab lanes
+  __shared__ float r0[16 * BN_SUBS], r1[16 * BN_SUBS];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;      // 16 columns x BN_SUBS slab lanes
   float a = 0.f, b = 0.f;
   if (col < c)
-    for (int k = sub; k < nblk; k += 16) {
+    for (int k = sub; k < nblk; k += BN_SUBS) {
       a += partial[(size_t)k * 2 * c + col];
       b += partial[(size_t)k * 2 * c + c + col];
     }
@@ -87,7 +91,7 @@ __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* 
   if (sub == 0 && col < c) {
     const int t = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < BN_SUBS; ++k) {
       s1 += r0[t + 16 * k];
       s2 += r1[t + 16 * k];
     }
@@ -109,11 +113,11 @@ __global__ void bn_stats_stage2(const float* __restrict__ partial, const float* 
 // stage 2 (backward): dbeta = sum dz, dgamma = sum dz*xhat
 __global__ void bn_bwd_stage2(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
                               int nblk, int c) {
-  __shared__ float r0[256], r1[256];
+  __shared__ float r0[16 * BN_SUBS], r1[16 * BN_SUBS];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;
   float a = 0.f, b = 0.f;
   if (col < c)
-    for (int k = sub; k < nblk; k += 16) {
+    for (int k = sub; k < nblk; k += BN_SUBS) {
       a += partial[(size_t)k * 2 * c + col];
       b += partial[(size_t)k * 2 * c + c + col];
     }
@@ -123,7 +127,7 @@ __global__ void bn_bwd_stage2(const float* __restrict__ partial, float* __restri
   if (sub == 0 && col < c) {
     const int t = threadIdx.x;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < BN_SUBS; ++k) {
       s1 += r0[t + 16 * k];
       s2 += r1[t + 16 * k];
     }
@@ -250,11 +254,11 @@ __global__ __launch_bounds__(256) void bn_bwd2_stage1(const float* __restrict__ 
 // coef[0..4][c] = ubar, w, p, q, T ; dgamma2[c] = invstd * N * T
 __global__ void bn_bwd2_stage2(const float* __restrict__ partial, const float* __restrict__ invstd,
                                float* __restrict__ coef, float* __restrict__ dgamma2, int nblk, int c, long rows) {
-  __shared__ float r[5][256];
+  __shared__ float r[5][16 * BN_SUBS];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15), sub = threadIdx.x >> 4;
   float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < c)
-    for (int k = sub; k < nblk; k += 16)
+    for (int k = sub; k < nblk; k += BN_SUBS)
       for (int j = 0; j < 5; ++j) a[j] += partial[((size_t)k * 5 + j) * c + col];
   for (int j = 0; j < 5; ++j) r[j][threadIdx.x] = a[j];
   __syncthreads();
@@ -262,7 +266,7 @@ __global__ void bn_bwd2_stage2(const float* __restrict__ partial, const float* _
     float t[5];
     for (int j = 0; j < 5; ++j) {
       float v = 0.f;
-      for (int k = 0; k < 16; ++k) v += r[j][threadIdx.x + 16 * k];
+      for (int k = 0; k < BN_SUBS; ++k) v += r[j][threadIdx.x + 16 * k];
       t[j] = v;
     }
     const float n = (float)rows;
@@ -346,7 +350,7 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3((int)nblk), dim3(256), 0, st, nullptr, x, nullptr, nullptr, nullptr, part,
                      rows, c, rpb, 0.f, 0);
-  hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, x, save_mean, save_invstd, running_mean,
+  hipLaunchKernelGGL(bn_stats_stage2, dim3(cdiv(c, 16)), dim3(16 * BN_SUBS), 0, st, part, x, save_mean, save_invstd, running_mean,
                      running_var, (int)nblk, c, rows, eps, momentum);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
@@ -368,7 +372,7 @@ int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const fl
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3((int)nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, part, rows,
                      c, rpb, slope, apply_act);
-  hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, dgamma, dbeta, (int)nblk, c);
+  hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 16)), dim3(16 * BN_SUBS), 0, st, part, dgamma, dbeta, (int)nblk, c);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
@@ -393,7 +397,7 @@ int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, co
   float* coef = part + (size_t)nblk * 5 * c;
   hipLaunchKernelGGL(bn_bwd2_stage1, dim3((int)nblk), dim3(256), 0, st, ddx, dy, x, y, save_mean, save_invstd, part, rows,
                      c, rpb, slope, apply_act);
-  hipLaunchKernelGGL(bn_bwd2_stage2, dim3(cdiv(c, 16)), dim3(256), 0, st, part, save_invstd, coef, g_gamma, (int)nblk, c,
+  hipLaunchKernelGGL(bn_bwd2_stage2, dim3(cdiv(c, 16)), dim3(16 * BN_SUBS), 0, st, part, save_invstd, coef, g_gamma, (int)nblk, c,
                      rows);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
