@@ -106,7 +106,7 @@ def lib():
             raise HipLibraryError(
                 'libsradsgan_hip.so is not built (%s). Build it with `make -C sradsgan_amd/csrc` or '
                 '`python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.' % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(os.environ.get('SRHIP_LIB', LIB_PATH))     # SRHIP_LIB: same-box A/B of two builds (debug)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
