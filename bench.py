@@ -609,7 +609,7 @@ def main():
     G, D, F = build_networks(device, seed=20240)             # identical initial replicas on every rank
     sync = dp.GradSync(world, force=force_dist) if (world > 1 or force_dist) else None
     step = TrainStep(G, D, F, grad_sync=sync, use_graph=(args.graph or os.environ.get('BENCH_GRAPH') == '1') and not args.no_graph,
-                     use_gp=os.environ.get('BENCH_NO_GP') != '1')
+                     use_gp=os.environ.get('BENCH_NO_GP') != '1', lr=float(os.environ.get('BENCH_LR', '2e-4')))   # BENCH_LR: diagnostic (0 freezes the weights)
     gen = torch.Generator().manual_seed(1234 + rank)         # disjoint synthetic shards per rank
     hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
     lr = torch.rand(B, 3, LR_SIDE, LR_SIDE, generator=gen).to(device)
