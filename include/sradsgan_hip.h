@@ -125,6 +125,15 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* d
                        size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw,
                        int stride, int pad, int ldx, int ldy, void* stream);
 
+/* The same for a conv with a fused LeakyReLU (sradsgan.py:476: D's 3 -> 64 head conv), from the gradient at the ACTIVATED
+ * output: dy * (y > 0 ? 1 : slope) is formed while dy is read, so no lrelu-backward pass is needed when only the weight and
+ * bias gradients of the layer are wanted.  srhip_conv2d_wgrad_act_ok says whether the shape is served (3-channel 3x3
+ * stride-1 convs at >= 65536 pixels); workspace as srhip_conv2d_wgrad_workspace. */
+int srhip_conv2d_wgrad_act_ok(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
+int srhip_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float slope, float* dw_oihw, float* db,
+                           void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw,
+                           int stride, int pad, int ldx, int ldy, void* stream);
+
 /* ---- bias gradient: db[c] = sum_rows dy[row][c]; workspace >= srhip_colsum_workspace() bytes -- */
 size_t srhip_colsum_workspace(long rows, int c);
 int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_bytes, long rows, int c,

@@ -197,4 +197,27 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, co
   return colsum_launch(dy, db, static_cast<char*>(workspace) + wbytes, (long)n * ho * wo, cout, ldy, as_stream(stream));
 }
 
+/* Weight + bias gradient of a conv whose output went through a fused LeakyReLU, from the gradient at the ACTIVATED output:
+ * dy_eff = dy * (y > 0 ? 1 : slope) is formed while dy is read (3-channel 3x3 stride-1 head convs at >= 65536 pixels only). */
+int srhip_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float slope, float* dw, float* db, void* workspace,
+                           size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride,
+                           int pad, int ldx, int ldy, void* stream) {
+  SRHIP_REQUIRE(x && dy && y && dw && db, "conv2d_wgrad_act: null tensor");
+  SRHIP_REQUIRE(!fast_wgrad_ok(cin, cout, kh, kw), "conv2d_wgrad_act: small-channel convs only");
+  const size_t need = srhip_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
+  if (!workspace || workspace_bytes < need) {
+    set_error("conv2d_wgrad_act: workspace %zu bytes < required %zu", workspace_bytes, need);
+    return SRHIP_ERR_WORKSPACE;
+  }
+  const size_t wbytes = align256(legacy_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad));
+  int bias_done = 0;
+  return legacy_conv2d_wgrad(x, dy, dw, workspace, wbytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy, stream, db,
+                             reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes), &bias_done, y, slope);
+}
+
+int srhip_conv2d_wgrad_act_ok(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  return (!fast_wgrad_ok(cin, cout, kh, kw) && cin <= 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (long)n * h * w >= 65536 &&
+          (size_t)3 * (w + 2) * cin * sizeof(float) <= 32 * 1024) ? 1 : 0;
+}
+
 }  // extern "C"

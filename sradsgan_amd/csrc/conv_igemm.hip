@@ -487,7 +487,12 @@ __global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restri
 // MFMAs.  The four waves take interleaved pixel pairs and are summed through LDS at the end.
 // bias_partial != nullptr: the bias gradient (column sums of dy) comes out of the same pass -- every dy value is in a
 // register here anyway; the separate colsum pass re-read the 382 MB of the 216 x 216 x 64 gradient (123 us, 7 per step).
+// ymask != nullptr: dy is the gradient at the conv's ACTIVATED output y = LeakyReLU(conv): the activation's backward
+// (dy * (y > 0 ? 1 : slope)) is applied to the values as they are loaded, so the separate lrelu-backward pass over the
+// 382 MB gradient (read dy, read y, write g: 150 us in the discriminator's serial chain, three passes per step) is not
+// needed when only the weight gradient of the layer is wanted.
 __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ ymask, float slope,
                                                               float* __restrict__ partial, float* __restrict__ bias_partial,
                                                               int N, int H, int W, int cin,
                                                               int cout, int ldx, int ldy, int rows_per_split) {
@@ -521,12 +526,17 @@ __global__ __launch_bounds__(256) void wgrad_smallcin_kernel(const float* __rest
     }
     __syncthreads();
     const float* drow = dy + (size_t)r * W * ldy + co0 + l31;
+    const float* yrow = ymask ? ymask + (size_t)r * W * ldy + co0 + l31 : nullptr;
 #pragma unroll 4
     for (int ow = 2 * wave; ow < W; ow += 8) {       // this wave's pixel pairs (ow, ow + 1)
       const int p = ow + half;
       const bool pok = p < W;
-      const float d0 = (pok && c0ok) ? drow[(size_t)p * ldy] : 0.f;
-      const float d1 = (pok && c1ok) ? drow[(size_t)p * ldy + 32] : 0.f;
+      float d0 = (pok && c0ok) ? drow[(size_t)p * ldy] : 0.f;
+      float d1 = (pok && c1ok) ? drow[(size_t)p * ldy + 32] : 0.f;
+      if (yrow != nullptr) {
+        if (pok && c0ok && !(yrow[(size_t)p * ldy] > 0.f)) d0 *= slope;
+        if (pok && c1ok && !(yrow[(size_t)p * ldy + 32] > 0.f)) d1 *= slope;
+      }
       const float b = (pok && koff >= 0) ? xs[p * cin + koff] : 0.f;
       bs0 += d0;
       bs1 += d1;
@@ -861,8 +871,11 @@ size_t legacy_conv2d_wgrad_bias_workspace(int n, int h, int w, int cin, int cout
 // legacy_conv2d_wgrad_bias_workspace bytes) and set *bias_done; otherwise the caller runs the column-sum pass.
 int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
                        int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
-                       void* stream, float* db, float* bias_ws, int* bias_done) {
+                       void* stream, float* db, float* bias_ws, int* bias_done, const float* ymask, float slope) {
   if (bias_done) *bias_done = 0;
+  SRHIP_REQUIRE(!ymask || (db && bias_ws && bias_done && cin <= 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 &&
+                           (long)n * h * w >= 65536 && (size_t)3 * (w + 2) * cin * sizeof(float) <= 32 * 1024),
+                "conv2d_wgrad: the fused activation mask is built for the 3-channel 3x3 head convs at full image size (with bias)");
   SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad: null tensor");
   SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                 "conv2d_wgrad: bad geometry");
@@ -893,7 +906,7 @@ int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* worksp
     ns = cdiv(rows, rps);
     const bool fuse_bias = db != nullptr && bias_ws != nullptr && bias_done != nullptr;
     hipLaunchKernelGGL(wgrad_smallcin_kernel, dim3(ns, cdiv(cout, 64)), dim3(256), (size_t)32 * 1024, st,
-                       x, dy, partial, fuse_bias ? bias_ws : nullptr, n, h, w, cin, cout, ldx, ldy, rps);
+                       x, dy, ymask, slope, partial, fuse_bias ? bias_ws : nullptr, n, h, w, cin, cout, ldx, ldy, rps);
     int rc0 = check_launch("wgrad_smallcin");
     if (rc0) return rc0;
     long total0 = (long)cout * g.Ktot;

@@ -16,7 +16,8 @@ size_t legacy_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int
 size_t legacy_conv2d_wgrad_bias_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
 int legacy_conv2d_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int n,
                         int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
-                        void* stream, float* db = nullptr, float* bias_ws = nullptr, int* bias_done = nullptr);
+                        void* stream, float* db = nullptr, float* bias_ws = nullptr, int* bias_done = nullptr,
+                        const float* ymask = nullptr, float slope = 0.f);
 
 // ---- fast path (conv_fast.hip): source channels % 16 == 0, <= 32 taps ------------------------- //
 // fprop/dgrad eligibility depends only on the conv's static shape, so the packed-weight layout

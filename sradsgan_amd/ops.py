@@ -408,6 +408,41 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
     return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
 
 
+_WGRAD_ACT = os.environ.get('SRHIP_WGRAD_ACT', '1') == '1'      # A/B knob
+
+
+def _wgrad_act_direct(w, b, x, dy, y, slope, stride, pad):
+    """Weight + bias gradient of a fused conv + LeakyReLU from the gradient at the activated output, accumulated into the
+    parameters' arena slots on the weight-gradient stream (srhip_conv2d_wgrad_act).  False when the shape is not served."""
+    cout, cin, kh, kw = w.shape
+    gw, gb = _grad_slot(w), _grad_slot(b)
+    if gw is None or gb is None:
+        return False
+    n, _, h, wd = x.shape
+    lib = _hip.lib()
+    if not lib.srhip_conv2d_wgrad_act_ok(n, h, wd, cin, cout, kh, kw, stride, pad):
+        return False
+    x, dy, y = nhwc(x), nhwc(dy), nhwc(y)
+    side = _state.wgrad_stream
+    cur = torch.cuda.current_stream()
+    run_on = side if side is not None else cur
+    if side is not None:
+        side.wait_stream(cur)
+    with torch.cuda.stream(run_on):
+        nbytes = lib.srhip_conv2d_wgrad_workspace(n, h, wd, cin, cout, kh, kw, stride, pad)
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, device=x.device, dtype=torch.float32)
+        dw = torch.empty(tuple(w.shape), device=x.device, dtype=torch.float32)
+        db = torch.empty(cout, device=x.device, dtype=torch.float32)
+        _hip.check(lib.srhip_conv2d_wgrad_act(_p(x), _p(dy), _p(y), float(slope), _p(dw), _p(db), _p(ws), ws.numel() * 4,
+                                              n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout, _stream()), 'conv2d_wgrad_act')
+        gw.add_(dw)
+        gb.add_(db)
+    if side is not None:
+        for t in (x, dy, y):
+            t.record_stream(side)
+    return True
+
+
 def colsum_raw(dy):
     """[N,C,H,W] (NHWC memory) -> [C] sum over N,H,W."""
     _require_gpu(dy, 'colsum')
@@ -477,9 +512,15 @@ class _ConvFwd(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y, b = ctx.saved_tensors
-        g = dy if ctx.slope is None else _LReluBwd.apply(dy, y, ctx.slope)
         skip = _skip_param_grads(w)
         need_dx = ctx.needs_input_grad[0] and x.data_ptr() not in _state.stop_ids
+        if ctx.slope is not None and not need_dx and not skip and ctx.needs_input_grad[1] and ctx.has_bias and \
+                ctx.needs_input_grad[2] and _state.direct_grads and not torch.is_grad_enabled() and _WGRAD_ACT and \
+                _wgrad_act_direct(w, b, x, dy, y, ctx.slope, ctx.stride, ctx.pad):
+            # head conv of the discriminator in the D step: only its parameter gradients are wanted, and the kernel applies the
+            # activation's backward while it reads dy -- no lrelu-backward pass over the 382 MB gradient in the serial chain
+            return None, None, None, None, None, None, None, None
+        g = dy if ctx.slope is None else _LReluBwd.apply(dy, y, ctx.slope)
         dx = _ConvDgrad.apply(g, w, tuple(x.shape), ctx.stride, ctx.pad) if need_dx else None
         dw = db = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not skip

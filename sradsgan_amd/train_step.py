@@ -104,6 +104,7 @@ class TrainStep:
         """sradsgan.py:595-641 ('L2' norm over channels => per-pixel, 'LS' penalty); returns the
         penalty with its double-backward graph attached (the caller backpropagates it)."""
         interp = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
+        self._interp = interp                 # the D step's backward does not need d/d(interp) again (backward_scope stop_at)
         d_out = self.D(interp)
         with ops.no_param_grads():
             (grads,) = torch.autograd.grad(d_out, interp, torch.ones_like(d_out), create_graph=True)
@@ -263,7 +264,7 @@ class TrainStep:
                 with ops.backward_scope(skip_params=d_params):
                     torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
                 self._exchange_start('G')
-            with ops.backward_scope(stop_at=(gen_hr,)):           # d/d(gen_hr) is not needed any more
+            with ops.backward_scope(stop_at=(gen_hr,) + ((self._interp,) if self.use_gp else ())):           # d/d(gen_hr) is not needed any more
                 self._backward_terms(terms, d_params)
             self._mark('D bwd done (main)')
             self._mark('D bwd done (D stream)', dside)
@@ -277,7 +278,7 @@ class TrainStep:
                 torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
             self._exchange_start('G')
             loss_D, gp, terms, fake = d_forward()
-            with ops.backward_scope(stop_at=(gen_hr,)):
+            with ops.backward_scope(stop_at=(gen_hr,) + ((self._interp,) if self.use_gp else ())):
                 self._backward_terms(terms, d_params)
         self._exchange_start('D')
         out = dict(loss_G=loss_G.detach(), loss_D=loss_D.detach(), pixel=pixel.detach(),

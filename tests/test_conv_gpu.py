@@ -355,6 +355,18 @@ def test_small_channel_kernels_at_full_image_size():
                                         dys_.to(dev).contiguous(memory_format=torch.channels_last), (cout_, cin_, 3, 3), 1, 1, True)
         assert _rel(dw_, refw_) < 5e-6, (cin_, cout_)
         assert _rel(db_, dys_.double().sum((0, 2, 3))) < 5e-6
+    # the same gradients from the gradient at the ACTIVATED output (srhip_conv2d_wgrad_act: LeakyReLU backward applied while dy
+    # is read), accumulated into existing .grad buffers as the training step does
+    wpar, bpar = torch.nn.Parameter(w0.to(dev)), torch.nn.Parameter(torch.zeros(64, device=dev))
+    wpar.grad, bpar.grad = torch.full_like(wpar, 0.5), torch.full_like(bpar, -0.25)
+    yact = torch.randn(n, 64, h, w, generator=g)
+    gmask = dy.double() * torch.where(yact.double() > 0, 1.0, 0.2)
+    refwa = torch.nn.grad.conv2d_weight(x3.double(), (64, 3, 3, 3), gmask, padding=1)
+    with ops.direct_param_grads(None), torch.no_grad():
+        assert ops._wgrad_act_direct(wpar, bpar, x3.to(dev).contiguous(memory_format=torch.channels_last), dyg,
+                                     yact.to(dev).contiguous(memory_format=torch.channels_last), 0.2, 1, 1)
+    assert _rel(wpar.grad - 0.5, refwa) < 5e-6
+    assert _rel(bpar.grad + 0.25, gmask.sum((0, 2, 3))) < 5e-6
     b0 = torch.randn(64, generator=g)                                  # head conv forward, bias + LeakyReLU
     refh = F.leaky_relu(F.conv2d(x3.double(), w0.double(), b0.double(), padding=1), 0.2)
     goth = ops.conv2d_fwd_raw(x3.to(dev).contiguous(memory_format=torch.channels_last), torch.nn.Parameter(w0.to(dev)), b0.to(dev), 1, 1, 0.2)
