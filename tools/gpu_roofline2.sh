@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for M in fp32 bf16x3 half; do
   O=$R/gpurun_out/roof2/$M
   mkdir -p $O
-  rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --roofline-only --no-sustained --conv-math $M > $O/kt.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --roofline-only --conv-math $M > $O/kt.log 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/bench.py --roofline-only --no-sustained --conv-math $M > $O/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py --roofline-only --no-sustained --conv-math $M > $O/write.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA -d $O/mfma -o p --output-format csv -- python3 $R/bench.py --roofline-only --no-sustained --conv-math $M > $O/mfma.log 2>&1
