@@ -262,20 +262,30 @@ def time_dominant_kernel(device, batch, sustained=True):
             continue
         with PowerSampler(device.index or 0) as ps:
             t_end = time.perf_counter() + 1.2
-            n = 0
-            while time.perf_counter() < t_end:
+            n, ev_ms, pairs = 0, 0.0, []
+            while time.perf_counter() < t_end:                  # HIP events around every batch of 100 launches, on the launch stream
+                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_ev.record()
                 for _ in range(100):
                     fn()
-                torch.cuda.synchronize()
+                e_ev.record()
+                pairs.append((s_ev, e_ev))
+                if len(pairs) >= 8:                             # keep the host at most 800 launches ahead
+                    pairs[0][1].synchronize()
+                    ev_ms += pairs[0][0].elapsed_time(pairs[0][1])
+                    pairs.pop(0)
                 n += 100
-            sus = (time.perf_counter() - (t_end - 1.2)) / n * 1e3
+            torch.cuda.synchronize()
+            for s_ev, e_ev in pairs:
+                ev_ms += s_ev.elapsed_time(e_ev)
+            sus = ev_ms / n
         pw = ps.summary()
         if pw is not None:
             pw['sustained_launch_ms'] = round(sus, 4)
             pw['frac_of_peak_at_sustained_clock'] = round(flops / (sus * 1e-3) / 1e12 / (peak * pw['sclk_mhz_mean'] / NOMINAL_SCLK_MHZ), 4)
         rec['power'] = pw
-        # `achieved` / `frac` are quoted on the average over this sustained loop (n launches, host wall clock around a drained
-        # device): it is the steady state of the kernel, and what rocprofv3 --kernel-trace --stats of the same command
+        # `achieved` / `frac` are quoted on the average over this sustained loop (n launches, HIP events around batches of
+        # 100 on the launch stream): it is the steady state of the kernel, and what rocprofv3 --kernel-trace --stats of the same command
         # averages to (profiles/).  The 50-launch burst and the drained-device figures stay in the record: they catch the
         # clock ramping up from idle and read 15 - 25 % longer.
         rec['avg_launch_ms'] = round(sus, 4)
