@@ -639,8 +639,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if os.environ.get('BENCH_MAIN_STREAM') == '1':              # experiment: the step on a non-default (non-blocking) stream
-        torch.cuda.set_stream(torch.cuda.Stream())
+    if os.environ.get('BENCH_MAIN_STREAM') in ('1', '2'):       # experiment: the step on a non-default (non-blocking) stream; 2: at high priority
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1 if os.environ['BENCH_MAIN_STREAM'] == '2' else 0))
     trace = []
     for _ in range(max(0, args.spinup_steps)):                  # untimed, before the contract's W warm-up steps
         step(lr, hr, alpha)
