@@ -52,6 +52,7 @@ def _side_streams(dev):
 
 class TrainStep:
     _timeline_on = False        # SRHIP_STEP_TIMELINE=1 (set per instance in __init__)
+    max_run_ahead = 0
 
     def __init__(self, generator, discriminator, feature_extractor, lr=2e-4, b1=0.9, b2=0.999,
                  weight_content=1e-2, weight_gan=1e-3, lambda_gp=10.0, clip_value=0.01, use_gp=True,
@@ -81,6 +82,8 @@ class TrainStep:
         self._capturing = False
         self._timeline_on = os.environ.get('SRHIP_STEP_TIMELINE') == '1'
         self.timeline = []
+        self.max_run_ahead = int(os.environ.get('SRHIP_RUN_AHEAD', '2'))     # steps the host may be ahead of the GPU (0: unbounded)
+        self._step_events = []
         self._calls = 0
         self._static = None
         self._d_params = self.arena_D.params
@@ -341,6 +344,17 @@ class TrainStep:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update
             self._update()
+            # Bound the host's run-ahead: the host enqueues a step in 35 - 50 ms, the GPU needs 61, so unchecked the host
+            # drifts steps ahead, and every block another stream touched (record_stream) stays unavailable until that
+            # stream's event has passed -- the allocator's reserved pool grew to 79 GB for 14 GB of live data
+            # (tools/mem_growth.py).  Waiting for the end of the step before the previous one keeps the GPU fed (one full
+            # step is always queued) and caps the pool.
+            if self.max_run_ahead > 0 and out['loss_G'].is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._step_events.append(ev)
+                if len(self._step_events) > self.max_run_ahead:
+                    self._step_events.pop(0).synchronize()
             return out
         if self._calls == 1:
             # first iteration runs eagerly on a side stream (library/allocator warm-up required before
