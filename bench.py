@@ -563,14 +563,41 @@ def self_launch(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # Watch ALL ranks (torchrun's behaviour): when one dies -- OOM, ncclCommInitRank failure, the WORLD_SIZE check -- the others
+    # would sit in the store rendezvous or in an RCCL collective forever, so the first non-zero exit ends the job; an overall
+    # deadline bounds a hang that kills nobody.
     rc = 0
+    deadline = time.monotonic() + float(os.environ.get('BENCH_LAUNCH_DEADLINE_S', '1500'))
     try:
-        for p in procs:
-            rc = p.wait() or rc
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print('bench.py: rank %d exited with code %d; stopping the other ranks' % (procs.index(p), code), file=sys.stderr)
+            if rc != 0:
+                break
+            if live and time.monotonic() > deadline:
+                print('bench.py: ranks still running at the launch deadline; stopping them', file=sys.stderr)
+                rc = 124
+                break
+            if live:
+                time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
-                p.kill()                                  # the exact children we started, never a pattern
+                p.terminate()                             # the exact children we started, never a pattern
+        t_kill = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
     return rc
 
 

@@ -393,7 +393,7 @@ def train_step(G, D, Fx, opt_G, opt_D, lr_img, hr_img, alpha, weight_content=1e-
         for p in D.parameters():
             p.clamp_(-clip_value, clip_value)
     return dict(loss_G=loss_G.item(), loss_D=loss_D.item(), pixel=pixel.item(), content=content.item(),
-                loss_gan=loss_gan.item(), gp=float(gp.detach()))
+                loss_gan=loss_gan.item(), gp=float(gp.detach()), gen_hr=gen_hr.detach())
 
 
 # --------------------------------------------------------------------------- #

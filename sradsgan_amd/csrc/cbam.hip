@@ -19,6 +19,15 @@
 
 namespace srhip {
 
+// max-pool comparisons propagate NaN like ATen's (adaptive_max_pool2d / max(dim)): a NaN beats every number, the first
+// NaN wins among NaNs -- a NaN activation in the discriminator must surface in the loss, not be masked by the gate
+__device__ __forceinline__ bool pool_takes(float v, float mx) { return v > mx || (v != v && mx == mx); }
+__device__ __forceinline__ bool pool_merge_takes(float om, int oi, float mx, int idx) {
+  const bool on = om != om, mn = mx != mx;
+  if (on || mn) return on && (!mn || oi < idx);
+  return om > mx || (om == mx && oi < idx);
+}
+
 // ---- along hw: one block per (image, 64 channels); thread = (channel, 1 of 4 pixel lanes) ---------------------- //
 template <bool FIXED>
 __global__ __launch_bounds__(256) void cbam_pool_hw_kernel(const float* __restrict__ x, float* __restrict__ t, int* __restrict__ arg,
@@ -34,7 +43,7 @@ __global__ __launch_bounds__(256) void cbam_pool_hw_kernel(const float* __restri
     for (int p = pl; p < hw; p += 4) {
       const float v = xp[(size_t)p * c];
       sum += v;
-      if (!FIXED && v > mx) {            // strict >: the first maximum of this lane's increasing p sequence
+      if (!FIXED && pool_takes(v, mx)) {   // strict >: the first maximum of this lane's increasing p sequence
         mx = v;
         idx = p;
       }
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(256) void cbam_pool_hw_kernel(const float* __restri
       for (int j = 1; j < 4; ++j) {
         const float mj = smax[cq + 64 * j];
         const int ij = sidx[cq + 64 * j];
-        if (mj > m || (mj == m && ij < ix)) {
+        if (pool_merge_takes(mj, ij, m, ix)) {
           m = mj;
           ix = ij;
         }
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void cbam_pool_c_kernel(const float* __restric
       const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (vv[e] > mx) {
+        if (pool_takes(vv[e], mx)) {
           mx = vv[e];
           idx = q * 4 + e;
         }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void cbam_pool_c_kernel(const float* __restric
     for (int o = 32; o > 0; o >>= 1) {
       const float om = __shfl_xor(mx, o, 64);
       const int oi = __shfl_xor(idx, o, 64);
-      if (om > mx || (om == mx && oi < idx)) {
+      if (pool_merge_takes(om, oi, mx, idx)) {
         mx = om;
         idx = oi;
       }

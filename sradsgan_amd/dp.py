@@ -15,6 +15,12 @@ import torch.distributed as dist
 
 ALIGN = 64                      # elements; keeps every parameter view 256-byte aligned in the arena
 
+# The RCCL communicator behind srhip_dp_* is ONE per process (csrc/dp_rccl.hip): GradSync objects share it.  _COMM_USERS counts
+# the objects that hold it (the last close() finalises it), _COMM_GENERATION numbers the communicators this process has
+# created so that the unique id of a destroyed communicator is never picked up from the rendezvous store again.
+_COMM_USERS = 0
+_COMM_GENERATION = 0
+
 
 class ParamArena:
     """Flat storage for one network's parameters, gradients and Adam state (sradsgan.py:724-725)."""
@@ -86,6 +92,12 @@ class GradSync:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.trace = []              # ('start' | 'finish', tag): the order the step drove the exchange in (tests)
         self._pending = {}           # tag -> event (device) or list of work handles (CPU)
+        self._deferred = {}          # tag -> flat arena whose exchange waits for finish() (host_sync mode)
+        import os
+        # Opt-in fallback until a run with more than one rank exists on hardware: nothing is enqueued ahead of
+        # its inputs -- start() only remembers the arena, finish() waits on the host for the producing streams, runs the
+        # collective and waits for it.  The known-good r1 behaviour; costs the overlap (the exchange is exposed, ~1 ms).
+        self.host_sync = os.environ.get('SRHIP_DP_HOST_SYNC') == '1'
         self._comm_stream = None
         self._rccl_ready = False
 
@@ -99,51 +111,65 @@ class GradSync:
 
     # ---- RCCL communicator behind the C ABI (device path) ------------------------------------------------------ #
     def init_rccl(self, device=None):
-        """Creates this process's RCCL communicator (srhip_dp_init).  Rank 0 draws the unique id and hands it to the
-        other ranks through torch.distributed's rendezvous store (no collective, no second communicator needed)."""
+        """Creates (or joins) this process's RCCL communicator (srhip_dp_init).  Rank 0 draws the unique id and hands it to
+        the other ranks through torch.distributed's rendezvous store (no collective, no second communicator needed), under a
+        key that carries the communicator's generation: after a close() the next communicator never reads a stale id."""
+        global _COMM_USERS, _COMM_GENERATION
         if self._rccl_ready:
             return
+        if self.group is not None:
+            raise NotImplementedError('GradSync: the device (RCCL) path runs over the default process group only; a sub-group '
+                                      'would need its own communicator and rendezvous key')
         import ctypes
+        import os
         from . import _hip
         lib = _hip.lib()
         if device is not None:
             torch.cuda.set_device(device)
-        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
         if lib.srhip_dp_world() == 0:
             nbytes = lib.srhip_dp_id_bytes()
             buf = ctypes.create_string_buffer(nbytes)
             if world > 1:
                 store = dist.distributed_c10d._get_default_store()
+                key = 'srhip_dp_unique_id/%d' % _COMM_GENERATION      # every rank creates its communicators in the same order
                 if rank == 0:
                     _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
-                    store.set('srhip_dp_unique_id', bytes(buf.raw))
+                    store.set(key, bytes(buf.raw))
                 else:
-                    raw = store.get('srhip_dp_unique_id')          # blocks until rank 0 has published it
+                    raw = store.get(key)                              # blocks until rank 0 has published it
                     buf = ctypes.create_string_buffer(bytes(raw), nbytes)
             else:
                 _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
             _hip.check(lib.srhip_dp_init(buf, rank, world), 'dp_init')
+            _COMM_GENERATION += 1
         if lib.srhip_dp_world() != world:
             raise RuntimeError('GradSync: RCCL communicator has %d ranks, torch.distributed %d' % (lib.srhip_dp_world(), world))
-        import os
         # HIGH priority: the exchange is enqueued tens of milliseconds ahead of its inputs, i.e. its stream sits on an
         # event wait for most of the step.  Measured on MI355X / ROCm 7.2 (single rank, tools/gpu_r2_dist.sh): parked on
         # a normal-priority queue that wait slows the compute streams' kernels by 12 % (75.1 vs 66.6 ms per step, with or
         # without an RCCL call behind it); on a high-priority queue the step costs 66.9 ms (+0.4 %).
         self._comm_stream = torch.cuda.Stream(priority=0 if os.environ.get('SRHIP_DP_PRIO') == '0' else -1)
         self._rccl_ready = True
+        _COMM_USERS += 1
 
     def rccl_ranks(self):
         from . import _hip
         return _hip.lib().srhip_dp_world() if self._rccl_ready else 0
 
     def close(self):
+        """Releases this object's hold on the process's communicator; the last holder finalises it (srhip_dp_finalize)."""
+        global _COMM_USERS
         if self._rccl_ready:
             from . import _hip
             torch.cuda.synchronize()
-            _hip.check(_hip.lib().srhip_dp_finalize(), 'dp_finalize')
             self._rccl_ready = False
+            self._pending.clear()
+            _COMM_USERS -= 1
+            if _COMM_USERS <= 0:
+                _COMM_USERS = 0
+                _hip.check(_hip.lib().srhip_dp_finalize(), 'dp_finalize')
 
     # ---- the exchange -------------------------------------------------------------------------------------------- #
     def start(self, tag, flat, after=()):
@@ -154,6 +180,11 @@ class GradSync:
             return
         if tag in self._pending:
             raise RuntimeError('GradSync.start(%r): the previous exchange of this arena was never finished' % (tag,))
+        if flat.is_cuda and self.host_sync:
+            self.init_rccl(flat.device)
+            self._deferred[tag] = (flat, [s.record_event() for s in (after or (torch.cuda.current_stream(),))])
+            self._pending[tag] = None
+            return
         if flat.is_cuda:
             import ctypes
             from . import _hip
@@ -179,6 +210,19 @@ class GradSync:
     def finish(self, tag):
         """Order everything enqueued afterwards on the current stream behind the exchange `tag`."""
         self.trace.append(('finish', tag))
+        if tag in self._deferred:                                   # host_sync mode: produce, exchange, consume -- serially
+            import ctypes
+            from . import _hip
+            flat, events = self._deferred.pop(tag)
+            self._pending.pop(tag, None)
+            for ev in events:
+                ev.synchronize()
+            comm = self._comm_stream
+            for b in self.buckets(flat):
+                _hip.check(_hip.lib().srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
+                                                                ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
+            comm.synchronize()
+            return
         pending = self._pending.pop(tag, None)
         if pending is None:
             return

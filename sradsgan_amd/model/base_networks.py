@@ -12,6 +12,9 @@ class _Clam(nn.Module):
 
     def __init__(self, in_planes, ratio=16, pool_mode='Avg|Max'):
         super().__init__()
+        if pool_mode != 'Avg|Max':               # fail at construction, not at the first forward (ops.clam has no single-pool variant)
+            raise NotImplementedError("CLAM / ChannelAttention: only pool_mode 'Avg|Max' is built by the SRADSGAN path "
+                                      "(sradsgan.py:669-671)")
         self.pool_mode = pool_mode
         self.fc1 = HipConv2d(in_planes, in_planes // ratio, 1, bias=False)
         self.fc2 = HipConv2d(in_planes // ratio, in_planes, 1, bias=False)
@@ -26,9 +29,11 @@ class _Slam(nn.Module):
     def __init__(self, kernel_size=7, pool_mode='Avg|Max'):
         super().__init__()
         assert kernel_size in (3, 7), 'kernel size must be 3 or 7'
+        if pool_mode != 'Avg|Max':
+            raise NotImplementedError("SLAM / SpatialAttention: only pool_mode 'Avg|Max' is built by the SRADSGAN path "
+                                      "(sradsgan.py:669-671)")
         self.pool_mode = pool_mode
-        cin = 2 if pool_mode == 'Avg|Max' else 1
-        self.conv1 = HipConv2d(cin, 1, kernel_size, padding=3 if kernel_size == 7 else 1, bias=False)
+        self.conv1 = HipConv2d(2, 1, kernel_size, padding=3 if kernel_size == 7 else 1, bias=False)
 
     def forward(self, x):
         return ops.slam(x, self.conv1.weight, self.pool_mode)
