@@ -385,6 +385,11 @@ def run_inference(args, device):
                       'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
 
 
+def _use_graph(args):
+    """--graph / BENCH_GRAPH=1: replay the three-stream compute part of the step from one captured hipGraph."""
+    return (args.graph or os.environ.get('BENCH_GRAPH') == '1') and not args.no_graph
+
+
 def run_chain(args, device):
     """BASELINE configs[4] on one GPU: the full training step at every scale of the chain sweep (HR tile 216 x 216, LR tile
     216 / s, per-GPU batch as given), default arithmetic 'half'.  One JSON line: per-scale img/s and ms/step, `value` = images
@@ -411,7 +416,7 @@ def run_chain(args, device):
                     m.bias.zero_()
         for m in (G, D, Fx):
             m.to(device)
-        step = TrainStep(G, D, Fx)
+        step = TrainStep(G, D, Fx, use_graph=_use_graph(args))
         gen = torch.Generator().manual_seed(1234 + sc)
         side = 216 // sc
         hr = torch.rand(B, 3, side * sc, side * sc, generator=gen).to(device)
@@ -442,7 +447,7 @@ def run_chain(args, device):
                       'ms_per_step': round(tot_t / (args.steps * len(scales)) * 1e3, 2), 'higher_is_better': True,
                       'dtype': DTYPE_LABEL[math], 'data': 'synthetic',
                       'config': {'workload': 'SRADSGAN full GAN training step at scales %s, HR 216x216, per-GPU batch %d' % (scales, B),
-                                 'conv_math': math, 'launch': 'eager'},
+                                 'conv_math': math, 'launch': 'hipGraph (three streams captured)' if _use_graph(args) else 'eager'},
                       'per_scale': per}), flush=True)
 
 
@@ -654,7 +659,7 @@ def main():
     B = int(os.environ.get('BENCH_BATCH', args.batch))
     G, D, F = build_networks(device, seed=20240)             # identical initial replicas on every rank
     sync = dp.GradSync(world, force=force_dist) if (world > 1 or force_dist) else None
-    step = TrainStep(G, D, F, grad_sync=sync, use_graph=(args.graph or os.environ.get('BENCH_GRAPH') == '1') and not args.no_graph,
+    step = TrainStep(G, D, F, grad_sync=sync, use_graph=_use_graph(args),
                      use_gp=os.environ.get('BENCH_NO_GP') != '1', lr=float(os.environ.get('BENCH_LR', '2e-4')))   # BENCH_LR: diagnostic (0 freezes the weights)
     gen = torch.Generator().manual_seed(1234 + rank)         # disjoint synthetic shards per rank
     hr = torch.rand(B, 3, LR_SIDE * SCALE, LR_SIDE * SCALE, generator=gen).to(device)
@@ -735,7 +740,7 @@ def main():
             'config': {'workload': 'SRADSGAN full GAN x4 training step (G+D+VGG perceptual, WGAN-GP), '
                                    'LR 54x54 -> HR 216x216, per-GPU batch %d' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
-                       'launch': 'hipGraph' if (args.graph and not args.no_graph) else 'eager'},
+                       'launch': 'hipGraph (three streams captured)' if _use_graph(args) else 'eager'},
             'losses_finite': finite, 'last_losses': {k: round(v, 6) for k, v in losses.items()},
             'step_tflops': round(value * GF_PER_IMG_ITER / 1e3, 2),
             'step_frac_of_mfma_peak': round(value * GF_PER_IMG_ITER / 1e3 / (MATH_PEAK[conv_math][0] * world), 4),

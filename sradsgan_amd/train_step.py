@@ -2,14 +2,17 @@
 (SRADSGAN/model/sradsgan.py:829-892) with identical arithmetic.
 
 Structure (MI355X-first, not the reference's call order):
-  compute   = zero grads; G forward, losses, backward; D forwards, gradient penalty, backward.
-              Every kernel of it is launched on one HIP stream and -- with use_graph=True -- captured
-              once into a hipGraph and replayed per iteration (the step is ~7000 launches; replay
-              removes the host from the critical path).
+  compute   = zero grads; G forward, losses, backward; D forwards, gradient penalty, backward: ~2600 kernel launches on
+              THREE HIP streams -- main (forward passes, data gradients), weight gradients, discriminator passes -- that
+              fork and join through events.  Eager by default; with use_graph=True the whole three-stream compute part is
+              captured once into ONE hipGraph (the side streams fork from and join the capturing stream, so their kernels
+              become parallel branches of the graph) and replayed per iteration: the host enqueues a step in a few
+              milliseconds instead of ~40 (the x8 / x9 steps are launch-bound in eager mode).
   exchange  = in-place bucketed all-reduce of the G and D gradient arenas over RCCL (only with
               world_size > 1; sradsgan_amd/dp.py GradSync) on its own HIP stream: G's arena is sent as soon as
               the generator's backward is enqueued and travels under the whole discriminator step, D's after
-              the discriminator's backward; the two Adam launches wait on the matching events.
+              the discriminator's backward; the two Adam launches wait on the matching events.  (Replayed from a graph
+              both arenas go out after the replay: the collectives stay outside the capture.)
   update    = one fused Adam kernel per network over its flat arena (srhip_adam_step), the D one
               also applying the weight clip (:891-892).
 
@@ -94,7 +97,7 @@ class TrainStep:
     # ------------------------------------------------------------------------------------------ #
     def _mark(self, name, stream=None):
         """SRHIP_STEP_TIMELINE=1: a timing event on `stream` (default: current), kept in self.timeline for tools/step_timeline.py."""
-        if self._timeline_on:
+        if self._timeline_on and not self._capturing:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(stream if stream is not None else torch.cuda.current_stream())
             self.timeline.append((self._calls, name, ev))
@@ -167,7 +170,7 @@ class TrainStep:
             return
         arena = self.arena_G if which == 'G' else self.arena_D
         streams = [torch.cuda.current_stream()] if arena.flat_g.is_cuda else []
-        if arena.flat_g.is_cuda and self.overlap_wgrad and not self.use_graph and self._wgrad_stream is not None:
+        if arena.flat_g.is_cuda and self.overlap_wgrad and self._wgrad_stream is not None:
             streams.append(self._wgrad_stream)                    # the weight-gradient kernels run there
         gs.start(which, arena.flat_g, after=streams)
 
@@ -182,7 +185,7 @@ class TrainStep:
         self._set_d_grad(True)
         self.arena_G.zero_grad()
         self.arena_D.zero_grad()
-        side = self._wgrad_stream if (self.overlap_wgrad and not self.use_graph) else None
+        side = self._wgrad_stream if self.overlap_wgrad else None
         if side is not None:
             # VGG features of the real batch depend on nothing the generator produces: compute them on the
             # side stream while the generator's forward runs (fills the partially occupied kernel tails)
@@ -317,7 +320,24 @@ class TrainStep:
         self._mark('update done')
 
     # ------------------------------------------------------------------------------------------ #
+    def _run_compute(self, imgs_lr, imgs_hr, alpha):
+        """The compute part on the current stream + the side streams, forked from and joined back into the current stream
+        (so the same code runs eagerly and under stream capture)."""
+        side = self._wgrad_stream if self.overlap_wgrad else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())     # arena zeroing / previous Adam before any wgrad
+        with ops.direct_param_grads(side):           # wgrad kernels accumulate straight into the gradient arenas
+            out = self._compute(imgs_lr, imgs_hr, alpha)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update
+        return out
+
     def _capture(self, imgs_lr, imgs_hr, alpha):
+        """Records the compute part -- all three streams -- into one hipGraph; nothing executes.  The side streams enter the
+        capture at their first wait on an event of the capturing stream and leave it at the joins at the end of
+        _compute_shared / _run_compute, so the capture ends with every forked stream joined (a HIP requirement).  Tensors
+        that cross streams carry record_stream marks: under capture the caching allocator keeps such blocks out of reuse
+        until the capture ends, which is exactly the lifetime the parallel branches need (costs pool memory, not time)."""
         self._static = dict(lr=imgs_lr.clone(), hr=imgs_hr.clone(), alpha=alpha.clone())
         self._graph = torch.cuda.CUDAGraph()
         dump = os.environ.get('SRHIP_GRAPH_DUMP')
@@ -325,46 +345,36 @@ class TrainStep:
             self._graph.enable_debug_mode()
         self._capturing = True
         try:
-            # same arithmetic as the eager path: weight-gradient kernels accumulate straight into the arenas, in program order
-            with torch.cuda.graph(self._graph), ops.direct_param_grads(None):
-                self._out = self._compute(self._static['lr'], self._static['hr'], self._static['alpha'])
+            # same arithmetic and the same per-stream program order as the eager path
+            with torch.cuda.graph(self._graph):
+                self._out = self._run_compute(self._static['lr'], self._static['hr'], self._static['alpha'])
         finally:
             self._capturing = False
         if dump:
             self._graph.debug_dump(dump)
 
+    def _bound_run_ahead(self, out):
+        # Bound the host's run-ahead: the host enqueues a step in 35 - 50 ms, the GPU needs 61, so unchecked the host
+        # drifts steps ahead, and every block another stream touched (record_stream) stays unavailable until that
+        # stream's event has passed -- the allocator's reserved pool grew to 79 GB for 14 GB of live data
+        # (tools/mem_growth.py).  Waiting for the end of the step before the previous one keeps the GPU fed (one full
+        # step is always queued) and caps the pool.  (Graph replays allocate nothing; the bound then only keeps the
+        # launch queue short.)
+        if self.max_run_ahead > 0 and out['loss_G'].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_events.append(ev)
+            if len(self._step_events) > self.max_run_ahead:
+                self._step_events.pop(0).synchronize()
+
     def __call__(self, imgs_lr, imgs_hr, alpha):
         self._calls += 1
-        if not self.use_graph:
-            side = self._wgrad_stream if self.overlap_wgrad else None
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())     # arena zeroing / previous Adam before any wgrad
-            with ops.direct_param_grads(side):       # wgrad kernels accumulate straight into the gradient arenas
-                out = self._compute(imgs_lr, imgs_hr, alpha)
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update
+        if not self.use_graph or self._calls == 1:
+            # (graph mode: the first iteration runs eagerly -- library, allocator and packed-weight warm-up must happen
+            # outside a capture; it is a real iteration, not a discarded one)
+            out = self._run_compute(imgs_lr, imgs_hr, alpha)
             self._update()
-            # Bound the host's run-ahead: the host enqueues a step in 35 - 50 ms, the GPU needs 61, so unchecked the host
-            # drifts steps ahead, and every block another stream touched (record_stream) stays unavailable until that
-            # stream's event has passed -- the allocator's reserved pool grew to 79 GB for 14 GB of live data
-            # (tools/mem_growth.py).  Waiting for the end of the step before the previous one keeps the GPU fed (one full
-            # step is always queued) and caps the pool.
-            if self.max_run_ahead > 0 and out['loss_G'].is_cuda:
-                ev = torch.cuda.Event()
-                ev.record()
-                self._step_events.append(ev)
-                if len(self._step_events) > self.max_run_ahead:
-                    self._step_events.pop(0).synchronize()
-            return out
-        if self._calls == 1:
-            # first iteration runs eagerly on a side stream (library/allocator warm-up required before
-            # stream capture); it is a real iteration, not a discarded one
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), ops.direct_param_grads(None):
-                out = self._compute(imgs_lr, imgs_hr, alpha)
-                self._update()
-            torch.cuda.current_stream().wait_stream(side)
+            self._bound_run_ahead(out)
             return out
         if self._graph is None:
             self._capture(imgs_lr, imgs_hr, alpha)           # records only; nothing executes
@@ -374,4 +384,5 @@ class TrainStep:
                     self._static[k].copy_(t)
         self._graph.replay()
         self._update()
+        self._bound_run_ahead(self._out)
         return self._out

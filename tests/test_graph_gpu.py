@@ -22,10 +22,10 @@ DEV = torch.device('cuda:0')
 NAMES = ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')
 
 
-def _run(use_graph, iters, sync_at):
+def _run(use_graph, iters, sync_at, three_streams=False):
     from sradsgan_amd.train_step import TrainStep
     (hg, hd, hf), _ = build_pair(2, 1, 4, DEV)
-    step = TrainStep(hg, hd, hf, use_graph=use_graph, overlap_wgrad=False, overlap_d_step=False)
+    step = TrainStep(hg, hd, hf, use_graph=use_graph, overlap_wgrad=three_streams, overlap_d_step=three_streams)
     batches = [(O.det_fill('graph.lr.%d' % (i % 3), (4, 3, 24, 24), 0.5, 0.5).to(DEV),
                 O.det_fill('graph.hr.%d' % (i % 3), (4, 3, 96, 96), 0.5, 0.5).to(DEV),
                 O.det_fill('graph.alpha.%d' % (i % 5), (4, 1, 1, 1), 0.5, 0.5).to(DEV)) for i in range(15)]
@@ -62,3 +62,23 @@ def test_graph_replay_is_independent_of_host_syncs_and_tracks_eager():
     assert float(rel.max()) == 0.0                       # and bit-identical to eager launches of the same program order
     for a, b in zip(synced_w, eager_w):
         assert torch.equal(a, b)
+
+
+def test_three_stream_capture_replays_bit_identically_to_the_three_stream_eager_step():
+    """The default step runs on three HIP streams (main, weight gradients, discriminator passes).  use_graph=True captures
+    all three into ONE hipGraph: the side streams fork from the capturing stream and join it again, their kernels become
+    parallel branches.  Per stream the program order is the eager one, so every accumulation meets its operands in the same
+    order: 56 iterations (1 eager warm-up + 55 replays) with device-wide synchronisations sprinkled in must be
+    BIT-IDENTICAL -- six scalars per iteration, final weights, BatchNorm buffers -- to the eager three-stream step, and
+    to the same replay without any synchronisation."""
+    iters = 56
+    sync_at = {1, 2} | set(range(7, iters, 7))
+    graph_s, graph_w = _run(True, iters, sync_at, three_streams=True)
+    free_s, free_w = _run(True, iters, set(), three_streams=True)
+    eager_s, eager_w = _run(False, iters, sync_at, three_streams=True)
+    assert torch.isfinite(graph_s).all()
+    for name, other_s, other_w in (('unsynchronised replay', free_s, free_w), ('eager three-stream step', eager_s, eager_w)):
+        bad = (graph_s != other_s).any(dim=1).nonzero().flatten().tolist()
+        assert not bad, ('three-stream graph differs from the ' + name, bad[:3], (graph_s[bad[0]] - other_s[bad[0]]).tolist())
+        for a, b in zip(graph_w, other_w):
+            assert torch.equal(a, b), name

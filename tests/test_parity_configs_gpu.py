@@ -71,6 +71,34 @@ def _psnr_gap(gen_hip, gen_ref, hr_img):
     return worst
 
 
+def _check_first_iteration_gradients(label, grads, ograds, scale, lr_side, batch, tag):
+    """First-iteration gradients (identical weights on both sides).  Bars of the x4 bench-configuration test against the fp32
+    oracle: G 5e-3, D 5e-2 (parity_util.grad_score).  Where that fails the quantity may simply be ill-conditioned -- at x8 the
+    group-tail bias gradients are near-cancelling sums over a 27 x 27 map and the fp32 ORACLE ITSELF is 6.5e-3 away from an
+    fp64 evaluation of the same graph (measured in the build container) --, so the referee becomes an fp64 run of the
+    oracle, with parity_util.train_parity's rule: G within max(5e-3, 3 x the fp32 oracle's own distance from fp64), D within
+    max(2e-2, 3 x the oracle's own distance)."""
+    sg, kg = grad_score((grads[0],), (ograds[0],), verbose=True)
+    sd, kd = grad_score((grads[1],), (ograds[1],), verbose=True)
+    print('%s: first-iteration gradients vs fp32 oracle: G %.3e (%s)  D %.3e (%s)' % (label, sg, kg, sd, kd))
+    if sg < 5e-3 and sd < 5e-2:
+        return
+    import copy
+    _, (og, od, of) = build_pair(12, 3, scale, torch.device('cpu'))
+    g64, d64, f64 = (copy.deepcopy(m).double() for m in (og, od, of))
+    lr_img, hr_img, alpha = _batch(tag, 0, batch, lr_side, scale)
+    O.train_step(g64, d64, f64, torch.optim.Adam(g64.parameters(), lr=2e-4), torch.optim.Adam(d64.parameters(), lr=2e-4),
+                 lr_img.double(), hr_img.double(), alpha.double())
+    sg, kg = grad_score((grads[0],), (g64,), verbose=True)
+    sd, kd = grad_score((grads[1],), (d64,), verbose=True)
+    rg, rkg = grad_score((ograds[0],), (g64,))
+    rd, rkd = grad_score((ograds[1],), (d64,))
+    g_bar, d_bar = max(5e-3, 3.0 * rg), max(2e-2, 3.0 * rd)
+    print('%s vs fp64 oracle: HIP G %.3e (%s) D %.3e (%s); the fp32 oracle itself G %.3e (%s) D %.3e (%s); bars G %.3e D %.3e'
+          % (label, sg, kg, sd, kd, rg, rkg, rd, rkd, g_bar, d_bar))
+    assert sg < g_bar and sd < d_bar, (sg, kg, g_bar, sd, kd, d_bar)
+
+
 @pytest.mark.parametrize('scale,lr_side', [(2, 108), (3, 72), (8, 27), (9, 24)])
 def test_full_training_step_at_real_tiles_against_oracle_in_both_arithmetics(scale, lr_side):
     B, iters, tag = 2, 2, 'real_x%d' % scale
@@ -95,10 +123,7 @@ def test_full_training_step_at_real_tiles_against_oracle_in_both_arithmetics(sca
         assert d < 1e-3, (it, scal[it], want[it])
         assert gap < 0.05
     assert rel_err(gens[0], want_gen[0]) < 1e-3
-    sg, kg = grad_score((grads[0],), (ograds[0],), verbose=True)
-    sd, kd = grad_score((grads[1],), (ograds[1],), verbose=True)
-    print('x%d @ LR %d bf16x3: first-iteration gradients vs fp32 oracle: G %.3e (%s)  D %.3e (%s)' % (scale, lr_side, sg, kg, sd, kd))
-    assert sg < 5e-3 and sd < 5e-2, (sg, kg, sd, kd)                 # the bars of the x4 bench-configuration test
+    _check_first_iteration_gradients('x%d @ LR %d bf16x3' % (scale, lr_side), grads, ograds, scale, lr_side, B, tag)
     # ---- 'half' arithmetic (configs[4]'s "fp16 MFMA"), judged against the same ORACLE run ----
     scal_h, gens_h, _ = _hip_iterations('half', tag, B, lr_side, scale, iters)
     for it in range(iters):
@@ -125,13 +150,13 @@ def test_bench_batch_32_one_iteration_against_oracle():
     wv = np.array([w[k] for k in NAMES])
     d = float(np.abs(scal[0] - wv).max())
     e = rel_err(gens[0], w['gen_hr'])
-    sg, kg = grad_score((grads[0],), (og,), verbose=True)
-    sd, kd = grad_score((grads[1],), (od,), verbose=True)
-    print('B = 32: scalars vs oracle %.3e (HIP %s), G output rel err %.3e, gradients G %.3e (%s) D %.3e (%s)'
-          % (d, scal[0], e, sg, kg, sd, kd))
+    print('B = 32: scalars vs oracle %.3e (HIP %s), G output rel err %.3e' % (d, scal[0], e))
     assert d < 1e-3, (scal[0], wv)
     assert e < 1e-3
     assert _psnr_gap(gens[0], w['gen_hr'], hr_img) < 0.05
+    sg, kg = grad_score((grads[0],), (og,), verbose=True)
+    sd, kd = grad_score((grads[1],), (od,), verbose=True)
+    print('B = 32: first-iteration gradients vs fp32 oracle: G %.3e (%s) D %.3e (%s)' % (sg, kg, sd, kd))
     assert sg < 5e-3 and sd < 5e-2, (sg, kg, sd, kd)
 
 

@@ -8,7 +8,8 @@ from sradsgan_amd.train_step import TrainStep
 dev = torch.device('cuda:0')
 B = int(os.environ.get('B', '32'))
 G, D, F = bench.build_networks(dev, 20240)
-step = TrainStep(G, D, F)
+step = TrainStep(G, D, F, use_graph=os.environ.get('GRAPH') == '1')
+step.max_run_ahead = 0          # measure the host alone: no waiting for the GPU inside the step
 gen = torch.Generator().manual_seed(1)
 hr = torch.rand(B, 3, 216, 216, generator=gen).to(dev); lr = torch.rand(B, 3, 54, 54, generator=gen).to(dev); al = torch.rand(B, 1, 1, 1, generator=gen).to(dev)
 for _ in range(8): step(lr, hr, al)
