@@ -44,7 +44,8 @@ int srhip_abi_version(void);
  * ABI 3: srhip_cgam_*, srhip_sgam_flash_*, loss reductions (srhip_l1_mean_*, srhip_mean_*, srhip_gp_norm_penalty_*),
  * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added;
  *        fast packed weights carry a third (fp16) section, SRHIP_MATH_HALF.
- * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed). */
+ * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed).
+ * ABI 5: srhip_bn_eval_fwd added (no existing entry point changed). */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
@@ -276,6 +277,11 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
 int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
                        size_t workspace_bytes, long rows, int c, float slope, int apply_act, void* stream);
+/* eval()-mode nn.BatchNorm2d (+ activation): the per-channel affine of the running statistics (SRGAN's generator at
+ * validation time, model/srgan.py; the SRADSGAN discriminator is never put in eval()).  Inference only.   */
+int srhip_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float* y, long rows, int c, float eps, float slope, int apply_act,
+                      void* stream);
 size_t srhip_bn_bwd2_workspace(long rows, int c);
 int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma,
                            const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,

@@ -70,6 +70,7 @@ SIGNATURES = {
     'srhip_mean_bwd': (_i, [_vp] * 2 + [_l, _vp]),
     'srhip_gp_norm_penalty_fwd': (_i, [_vp] * 3 + [_sz, _l, _i, _vp]),
     'srhip_gp_norm_penalty_bwd': (_i, [_vp] * 3 + [_l, _i, _vp]),
+    'srhip_bn_eval_fwd': (_i, [_vp] * 6 + [_l, _i, _f, _f, _i, _vp]),
     'srhip_dp_id_bytes': (_i, []),
     'srhip_dp_unique_id': (_i, [_vp]),
     'srhip_dp_init': (_i, [_vp, _i, _i]),

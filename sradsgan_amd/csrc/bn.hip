@@ -165,6 +165,27 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// eval(): y = act((x - running_mean) / sqrt(running_var + eps) * gamma + beta) -- a per-channel affine
+__global__ void bn_eval_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                               const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                               long n4, int c, float eps, float slope, int act) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    const int ch = (int)((i * 4) % c);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float is = 1.0f / sqrtf(var[ch + e] + eps);
+      o[e] = (vv[e] - mean[ch + e]) * is * gamma[ch + e] + beta[ch + e];
+      if (act) o[e] = o[e] > 0.f ? o[e] : o[e] * slope;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // dx = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                     const float* __restrict__ y, const float* __restrict__ mean,
@@ -358,6 +379,19 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, n4, c,
                      slope, apply_act);
   return check_launch("bn_train_fwd");
+}
+
+int srhip_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float* y, long rows, int c, float eps, float slope, int apply_act,
+                      void* stream) {
+  SRHIP_REQUIRE(x && gamma && beta && running_mean && running_var && y, "bn_eval_fwd: null tensor");
+  SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0, "bn_eval_fwd: C must be a multiple of 4");
+  const long n4 = rows * c / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, running_mean, running_var, gamma, beta, y,
+                     n4, c, eps, slope, apply_act);
+  return check_launch("bn_eval_fwd");
 }
 
 int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,

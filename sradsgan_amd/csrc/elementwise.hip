@@ -230,7 +230,7 @@ using namespace srhip;
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 4; }
+int srhip_abi_version(void) { return 5; }
 
 int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream) {
   SRHIP_REQUIRE(dy && y && dx && count >= 0, "lrelu_bwd: bad argument");

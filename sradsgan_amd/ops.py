@@ -149,7 +149,9 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream: torch.cuda.current_stream() builds a Stream object per call (~9 us, 300
+    # calls per step on each of the two launching threads)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 class _PackRegistry:
@@ -1172,12 +1174,18 @@ def batch_norm_act(x, bn, slope=None):
     running statistics like nn.BatchNorm2d (momentum 0.1, unbiased running_var).  Twice differentiable."""
     if not bn.training:
         # eval(): running statistics, a per-channel affine (SRGAN's generator at validation time; the SRADSGAN
-        # discriminator is never put in eval(), SURVEY a11)
+        # discriminator is never put in eval(), SURVEY a11).  Inference only: srhip_bn_eval_fwd has no backward.
         _require_gpu(x, 'batch_norm')
-        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-        shift = bn.bias - bn.running_mean * scale
-        y = nhwc(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
-        return y if slope is None else torch.nn.functional.leaky_relu(y, float(slope))
+        if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+            raise NotImplementedError('batch_norm_act: eval()-mode BatchNorm is built for inference only (wrap the call in '
+                                      'torch.no_grad()); training through frozen statistics is not on the SRADSGAN path')
+        xc = nhwc(x)
+        n, c, h, w = xc.shape
+        y = torch.empty_like(xc, memory_format=CL)
+        _hip.check(_hip.lib().srhip_bn_eval_fwd(_p(xc), _p(bn.weight.detach().contiguous()), _p(bn.bias.detach().contiguous()),
+                                                _p(bn.running_mean), _p(bn.running_var), _p(y), n * h * w, c, float(bn.eps),
+                                                float(slope or 0.0), int(slope is not None), _stream()), 'bn_eval_fwd')
+        return y
     y = _BNTrainFwd.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
     with torch.no_grad():
         bn.num_batches_tracked += 1
@@ -1233,7 +1241,8 @@ class _MaxPool2x2(Function):
 def max_pool2x2(x):
     if x.shape[1] % 4 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
         return _MaxPool2x2.apply(x)
-    return torch.nn.functional.max_pool2d(x, 2, 2)
+    raise NotImplementedError('max_pool2x2: the HIP kernel takes C %% 4 == 0 and even H, W (VGG on 216 x 216 tiles); got %s -- '
+                              'there is no ATen fallback' % (tuple(x.shape),))
 
 
 class _VggFeatures(Function):

@@ -70,7 +70,7 @@ class TrainStep:
         self.grad_sync = grad_sync                       # dp.GradSync or None
         self.use_graph = use_graph
         self.reuse_d_fake = reuse_d_fake
-        self.overlap_wgrad = overlap_wgrad
+        self.overlap_wgrad = overlap_wgrad = overlap_wgrad and os.environ.get('SRHIP_OVERLAP_WGRAD', '1') == '1'     # A/B knob
         self.overlap_d_step = overlap_d_step and os.environ.get('SRHIP_OVERLAP_D', '1') == '1'
         if self.overlap_d_step and hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
             # D's parameters are used on both streams by design; the engine orders their AccumulateGrad nodes itself
