@@ -1133,6 +1133,10 @@ class _BNTrainBwd(Function):
                                                   _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(ws),
                                                   ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
                                                   int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
+            slot = None if _skip_param_grads(gamma) else _grad_slot(gamma)
+            if slot is not None:                        # direct_param_grads(): straight into the arena, on this node's stream
+                slot.add_(g_gamma)
+                g_gamma = None
             return g_dy, g_x, None, g_gamma, None, None, None, None
         with torch.enable_grad():
             dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
@@ -1159,13 +1163,22 @@ class _BNTrainFwd(Function):
                                           ws.numel() * 4, rows, c, float(eps), float(momentum), float(slope or 0.0),
                                           int(slope is not None), _stream()), 'bn_train_fwd')
         ctx.eps, ctx.slope = eps, slope
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.save_for_backward(x, y, gamma, mean, invstd, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope)
+        if not torch.is_grad_enabled() and not _skip_param_grads(gamma, beta):
+            # direct_param_grads(): add into the arena slots here, on the stream this node runs on, instead of handing the
+            # gradients to autograd -- its AccumulateGrad nodes run on the stream the parameter was FIRST used on in this
+            # iteration (the main stream, D(gen_hr)), which would make the main stream wait for the D stream's backward
+            gg, gb = _grad_slot(gamma), _grad_slot(beta)
+            if gg is not None and gb is not None:
+                gg.add_(dgamma)
+                gb.add_(dbeta)
+                return dx, None, None, None, None, None, None, None
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -1193,7 +1206,7 @@ def batch_norm_act(x, bn, slope=None):
     if stash is not None and y.grad_fn is not None:
         # (batch mean, invstd, count) of this call, so the caller can replay the running-statistics update
         # of a forward pass it does not recompute (TrainStep: D(fake) == D(gen_hr))
-        x_, y_, g_, mean, invstd = y.grad_fn.saved_tensors
+        x_, y_, g_, mean, invstd, b_ = y.grad_fn.saved_tensors
         stash.append((bn, mean, invstd, x.numel() // x.shape[1]))
     return y
 

@@ -261,17 +261,42 @@ class TrainStep:
             else:
                 dside.wait_stream(main)
             self._mark('D passes begin (D stream)', dside)
+            early = self.use_gp and os.environ.get('SRHIP_D_EARLY', '1') == '1' and not late
+            stop = (gen_hr,) + ((self._interp,) if self.use_gp else ())
             with torch.cuda.stream(dside):
                 loss_D, gp, terms, fake = d_forward()
-            self._mark('D passes + GP first order done (D stream)', dside)
+                self._mark('D passes + GP first order done (D stream)', dside)
+                if early:
+                    # The real pass and the penalty live entirely on the D stream and do not depend on the generator's
+                    # backward: walk them HERE, with the D stream as the calling stream.  (Called from the main stream after
+                    # the generator's backward, the root gradient of each term is produced at that point of the MAIN
+                    # stream's queue, so the D stream sat idle from ~27 ms to ~48 ms of a 60 ms step and its serial
+                    # data-gradient / BatchNorm chain became a 10 - 15 ms tail, tools/step_timeline.py.)  Their weight-gradient
+                    # kernels run in line on the D stream -- the weight-gradient stream is one queue in host order, and
+                    # these would block the generator's weight gradients behind kernels that wait for the D stream.
+                    with ops.direct_param_grads(None), ops.backward_scope(stop_at=stop):
+                        self._backward_terms([terms[0], terms[2]], d_params)
+                    self._mark('D bwd of the real + penalty terms done (D stream)', dside)
             for t in (gen_hr, d_gen, alpha):
                 t.record_stream(dside)
             if not late:
                 with ops.backward_scope(skip_params=d_params):
                     torch.autograd.backward(loss_G, inputs=g_params, retain_graph=True)
                 self._exchange_start('G')
-            with ops.backward_scope(stop_at=(gen_hr,) + ((self._interp,) if self.use_gp else ())):           # d/d(gen_hr) is not needed any more
-                self._backward_terms(terms, d_params)
+                self._mark('G bwd done (main)')
+            if early:
+                # D's arena: the fake term's contributions (weight gradients on the weight-gradient stream, BatchNorm's in line
+                # on the main stream) after the D stream's
+                side.wait_stream(dside)
+                main.wait_stream(dside)
+                with ops.backward_scope(stop_at=stop):
+                    self._backward_terms([terms[1]], d_params)
+            else:
+                with ops.backward_scope(stop_at=stop):           # d/d(gen_hr) is not needed any more
+                    for t in terms:                              # real (D stream), fake (main), penalty (D stream): one
+                        self._backward_terms([t], d_params)      # after the other -- they add into the same arena slots
+                        main.wait_stream(dside)
+                        dside.wait_stream(main)
             self._mark('D bwd done (main)')
             self._mark('D bwd done (D stream)', dside)
             self._mark('wgrads done (wgrad stream)', side)
