@@ -262,9 +262,9 @@ class TrainStep:
                 dside.wait_stream(main)
             self._mark('D passes begin (D stream)', dside)
             early = self.use_gp and os.environ.get('SRHIP_D_EARLY', '1') == '1' and not late
-            stop = (gen_hr,) + ((self._interp,) if self.use_gp else ())
             with torch.cuda.stream(dside):
                 loss_D, gp, terms, fake = d_forward()
+                stop = (gen_hr,) + ((self._interp,) if self.use_gp else ())      # (gradient_penalty sets _interp)
                 self._mark('D passes + GP first order done (D stream)', dside)
                 if early:
                     # The real pass and the penalty live entirely on the D stream and do not depend on the generator's

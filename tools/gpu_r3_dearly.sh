@@ -17,10 +17,9 @@ run early_b SRHIP_D_EARLY=1
 run late_b SRHIP_D_EARLY=0
 SRHIP_D_EARLY=1 timeout 200 python tools/step_timeline.py > $O/timeline_early.txt 2>&1; cat $O/timeline_early.txt | tail -14
 SRHIP_D_EARLY=0 timeout 200 python tools/step_timeline.py > $O/timeline_late.txt 2>&1; cat $O/timeline_late.txt | tail -13
-for sc in 8,9; do
-  for v in "X=1" "BENCH_GRAPH=1 SRHIP_OVERLAP_WGRAD=0"; do
-    env $v timeout 300 python bench.py --workload chain --scales $sc --conv-math bf16x3 --steps 20 --warmup 5 --spinup-steps 10 | python -c "
+for v in "SRHIP_D_EARLY=1" "SRHIP_D_EARLY=0"; do
+  env $v timeout 300 python bench.py --workload chain --scales 2,3,8,9 --conv-math bf16x3 --steps 12 --warmup 4 --spinup-steps 10 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', {k:(v['ms_per_step']) for k,v in d['per_scale'].items()})"
-  done
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/loop_shape.hip -o /tmp/loop_shape 2>/dev/null && timeout 120 /tmp/loop_shape | tee $O/loop_shape.txt
