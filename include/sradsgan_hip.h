@@ -45,7 +45,7 @@ int srhip_abi_version(void);
  * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added;
  *        fast packed weights carry a third (fp16) section, SRHIP_MATH_HALF.
  * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed).
- * ABI 5: srhip_bn_eval_fwd added (no existing entry point changed). */
+ * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace) added (no existing entry point changed). */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
@@ -181,6 +181,15 @@ size_t srhip_attn_tail_mlp_workspace(int n, int hidden);
 int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, const float* s, const float* fc1,
                             const float* fc2, float* davg, float* dmax, float* dfc1, float* dfc2, int accumulate_dfc,
                             void* workspace, size_t workspace_bytes, int n, int c, int hidden, void* stream);
+/* The three calls above as ONE (7 launches instead of 10 in the serial chain of every RAB / ResGroup backward; identical
+ * arithmetic and summation orders): dz = gradient at z (from srhip_conv2d_dgrad of the 1x1 conv), everything else as saved
+ * by srhip_attn_tail_fwd.  dw7 / dfc1 / dfc2 are written, or accumulated into when the flag is set.        */
+size_t srhip_attn_tail_bwd_fused_workspace(int n, int h, int w, int hidden);
+int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
+                        const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
+                        const float* fc2, float* du, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
+                        int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
+                        void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

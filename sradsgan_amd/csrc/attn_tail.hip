@@ -308,12 +308,27 @@ __global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, f
 // ---- B3: dy = m*dz + dpooled.x/C + [c == argc]*dpooled.y ; du = s*dy ; ds partial = sum_pix dy*u --- //
 // grid = (blocks_per_image, B); each block walks pixels of ONE image; 256 threads = 16 pixel lanes x 16
 // channel quads; dsp[b][blk][c] holds the block's partial of ds.
+// FOLD: the grid carries one extra block column; its block of image 0 does slam_conv7_wgrad_reduce_kernel's work (same
+// summation order), the other blocks of that column exit -- one launch less in the serial chain of every tail.
+template <bool FOLD>
 __global__ void tail_bwd_main_kernel(const float* __restrict__ dz, const float* __restrict__ u,
                                      const float* __restrict__ s, const float* __restrict__ m,
                                      const float2* __restrict__ dpooled, const int* __restrict__ argc,
-                                     float* __restrict__ du, float* __restrict__ dsp, int hw) {
+                                     float* __restrict__ du, float* __restrict__ dsp, int hw,
+                                     const float* __restrict__ w7part, float* __restrict__ dw7, int w7blk, int acc7) {
   __shared__ float4 red[256];
-  const int b = blockIdx.y, nblk = gridDim.x;
+  const int b = blockIdx.y, nblk = FOLD ? gridDim.x - 1 : gridDim.x;
+  if (FOLD && blockIdx.x == nblk) {
+    if (b != 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = wv; t < 98; t += 4) {
+      float a = 0.f;
+      for (int k = lane; k < w7blk; k += 64) a += w7part[(size_t)t * w7blk + k];
+      a = wave_sum(a);
+      if (lane == 0) dw7[t] = acc7 ? dw7[t] + a : a;
+    }
+    return;
+  }
   const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
   const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -360,8 +375,22 @@ __global__ void tail_bwd_ds_kernel(const float* __restrict__ dsp, float* __restr
 }
 
 // ---- B5: du += davg[b,c]/HW + [pix == argmax_hw[b,c]] * dmax[b,c]  (in place) ----------------------- //
+// pw1 != nullptr: blocks past the pixel range do clam_mlp_bwd_reduce_kernel's work (same order).
 __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restrict__ davg,
-                                    const float* __restrict__ dmax, const int* __restrict__ arg, int hw, long npix) {
+                                    const float* __restrict__ dmax, const int* __restrict__ arg, int hw, long npix,
+                                    int pix_blocks, const float* __restrict__ pw1, const float* __restrict__ pw2,
+                                    float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden, int accfc) {
+  if ((int)blockIdx.x >= pix_blocks) {
+    const int i = ((int)blockIdx.x - pix_blocks) * blockDim.x + threadIdx.x;
+    const int per = hidden * TC;
+    if (i >= 2 * per) return;
+    const float* src = i < per ? pw1 + i : pw2 + (i - per);
+    float acc = 0.f;
+    for (int b = 0; b < n; ++b) acc += src[(size_t)b * per];
+    float* o = i < per ? dfc1 + i : dfc2 + (i - per);
+    *o = accfc ? *o + acc : acc;
+    return;
+  }
   const long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int cq = threadIdx.x & 15;
   if (pix >= npix) return;
@@ -382,15 +411,23 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
 // ---- B4b: backward of s = sigmoid(W2 relu(W1 avg) + W2 relu(W1 max)) for one image per block ------- //
 // ds [B][64] -> davg, dmax [B][64] and per-image partials of dW1 [H][64], dW2 [64][H] (summed by the
 // reduce kernel below).  64 threads = 64 channels; H <= 16.
+// nblk > 0: `ds` holds tail_bwd_main_kernel's block partials [b][nblk][c]; they are summed here in tail_bwd_ds_kernel's order.
 __global__ void clam_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ avg,
                                     const float* __restrict__ mx, const float* __restrict__ s,
                                     const float* __restrict__ fc1, const float* __restrict__ fc2,
                                     float* __restrict__ davg, float* __restrict__ dmax, float* __restrict__ pw1,
-                                    float* __restrict__ pw2, int hidden) {
+                                    float* __restrict__ pw2, int hidden, int nblk) {
   __shared__ float sa[TC], sm[TC], sdl[TC], pa[16], pm[16], dpa[16], dpm[16];
   const int b = blockIdx.x, c = threadIdx.x;
   const float sv = s[b * TC + c];
-  const float dl = ds[b * TC + c] * sv * (1.f - sv);
+  float dsv;
+  if (nblk > 0) {
+    dsv = 0.f;
+    for (int k = 0; k < nblk; ++k) dsv += ds[((size_t)b * nblk + k) * TC + c];
+  } else {
+    dsv = ds[b * TC + c];
+  }
+  const float dl = dsv * sv * (1.f - sv);
   const float a_ = avg[b * TC + c], m_ = mx[b * TC + c];
   sa[c] = a_;
   sm[c] = m_;
@@ -488,7 +525,7 @@ int srhip_attn_tail_bwd_spatial(const float* dz, const float* u, const float* s,
   SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd_spatial: image too wide for the 7x7 weight-gradient strip");
   hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), w7lds, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, strips);
   hipLaunchKernelGGL(slam_conv7_wgrad_reduce_kernel, dim3(98), dim3(64), 0, st, w7part, dw7, w7blk, accumulate_dw7);
-  hipLaunchKernelGGL(tail_bwd_main_kernel, dim3(TAIL_BLK, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw);
+  hipLaunchKernelGGL(tail_bwd_main_kernel<false>, dim3(TAIL_BLK, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw, nullptr, nullptr, 0, 0);
   hipLaunchKernelGGL(tail_bwd_ds_kernel, dim3(n), dim3(TC), 0, st, dsp, ds, TAIL_BLK);
   return check_launch("attn_tail_bwd_spatial");
 }
@@ -500,8 +537,52 @@ int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax,
   SRHIP_REQUIRE(du && davg && dmax && argmax_hw && c == TC && n > 0 && h > 0 && w > 0, "attn_tail_bwd_channel: bad argument");
   const int hw = h * w;
   const long npix = (long)n * hw;
-  hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, as_stream(stream), du, davg, dmax, argmax_hw, hw, npix);
+  hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, as_stream(stream), du, davg, dmax, argmax_hw, hw, npix,
+                     (int)cdiv(npix, 16), nullptr, nullptr, nullptr, nullptr, 0, 0, 0);
   return check_launch("attn_tail_bwd_channel");
+}
+
+// The whole backward of the tail behind the 1x1 conv's data gradient in ONE call and 7 launches (the three entry points
+// above: 10): the 7x7 weight-gradient reduce rides in an extra block column of the main pass, the sum of the ds partials
+// in the MLP-backward kernel, the MLP weight-gradient reduce in extra blocks of the final fix-up pass.  Same arithmetic
+// and summation orders as the separate kernels (bit-identical results).
+size_t srhip_attn_tail_bwd_fused_workspace(int n, int h, int w, int hidden) {
+  return srhip_attn_tail_bwd_workspace(n, h, w) + ((size_t)n * 2 * hidden * TC + 2 * (size_t)n * TC) * sizeof(float);
+}
+
+int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
+                        const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
+                        const float* fc2, float* du, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
+                        int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
+                        void* stream) {
+  SRHIP_REQUIRE(dz && u && s && m && pooled && argc && avg && mx && argmax_hw && w7 && fc1 && fc2 && du && dw7 && dfc1 && dfc2,
+                "attn_tail_bwd: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_bwd: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_bwd_fused_workspace(n, h, w, hidden), "attn_tail_bwd: workspace too small");
+  const int hw = h * w;
+  const long npix = (long)n * hw;
+  hipStream_t st = as_stream(stream);
+  float* da = static_cast<float*>(workspace);
+  float2* dpooled = reinterpret_cast<float2*>(da + npix);
+  float* dsp = da + 3 * npix;
+  float* w7part = dsp + (size_t)n * TAIL_BLK * TC;
+  const int strips = (int)cdiv(h, W7_ROWS), w7blk = n * strips;
+  float* pw1 = w7part + (size_t)w7blk * 98;
+  float* pw2 = pw1 + (size_t)n * hidden * TC;
+  float* davg = pw2 + (size_t)n * hidden * TC;
+  float* dmax = davg + (size_t)n * TC;
+  const size_t w7lds = ((size_t)W7_ROWS * w + 2 * (size_t)(W7_ROWS + 6) * (w + 6)) * sizeof(float);
+  SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd: image too wide for the 7x7 weight-gradient strip");
+  hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
+  hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
+  hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), w7lds, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, strips);
+  hipLaunchKernelGGL(tail_bwd_main_kernel<true>, dim3(TAIL_BLK + 1, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw,
+                     w7part, dw7, w7blk, accumulate_dw7);
+  hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
+  const int pix_blocks = (int)cdiv(npix, 16), red_blocks = (int)cdiv(2 * hidden * TC, 256);
+  hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(pix_blocks + red_blocks), dim3(256), 0, st, du, davg, dmax, argmax_hw, hw, npix, pix_blocks,
+                     pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc);
+  return check_launch("attn_tail_bwd");
 }
 
 size_t srhip_attn_tail_mlp_workspace(int n, int hidden) { return (size_t)n * 2 * hidden * TC * sizeof(float); }
@@ -515,7 +596,7 @@ int srhip_attn_tail_bwd_mlp(const float* ds, const float* avg, const float* mx, 
   hipStream_t st = as_stream(stream);
   float* pw1 = static_cast<float*>(workspace);
   float* pw2 = pw1 + (size_t)n * hidden * TC;
-  hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, ds, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden);
+  hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, ds, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, 0);
   hipLaunchKernelGGL(clam_mlp_bwd_reduce_kernel, dim3(cdiv(2 * hidden * TC, 256)), dim3(256), 0, st, pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc);
   return check_launch("attn_tail_bwd_mlp");
 }

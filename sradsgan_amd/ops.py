@@ -633,6 +633,9 @@ def pixel_shuffle_act(x, r, slope=None):
 # --------------------------------------------------------------------------------------------- #
 
 
+_TAIL_FUSED = os.environ.get('SRHIP_TAIL_FUSED', '1') == '1'
+
+
 def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
     """returns (out, tensors to save for _tail_backward)."""
     n, c, h, w = u.shape
@@ -663,32 +666,36 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
     if not skip_params:
         dwc, dbc = wgrad_for_params(wc, bc, u, g, 1, 0, has_bias, m, s)             # x operand = z, rebuilt on the fly
     du = torch.empty_like(u, memory_format=CL)
-    ds = torch.empty(n, c, **f32)
-    g7 = None if skip_params else _grad_slot(w7)
-    dw7 = g7 if g7 is not None else torch.empty(w7.shape, **f32)
-    ws = torch.empty(lib.srhip_attn_tail_bwd_workspace(n, h, w) // 4, **f32)
-    _hip.check(lib.srhip_attn_tail_bwd_spatial(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc),
-                                               _p(w7.detach().contiguous()), _p(du), _p(ds), _p(dw7),
-                                               int(g7 is not None), _p(ws), ws.numel() * 4, n, h, w, c, _stream()),
-               'attn_tail_bwd_spatial')
-    if g7 is not None:
-        dw7 = None
-    # channel half: ds -> sigmoid -> shared MLP -> (davg, dmax, dfc1, dfc2), one block per image
     hid = fc1_w.shape[0]
-    davg, dmax = torch.empty(n, c, **f32), torch.empty(n, c, **f32)
+    g7 = None if skip_params else _grad_slot(w7)
     g1, g2 = (None, None) if skip_params else (_grad_slot(fc1_w), _grad_slot(fc2_w))
     direct = g1 is not None and g2 is not None
+    dw7 = g7 if g7 is not None else torch.empty(w7.shape, **f32)
     dfc1 = g1 if direct else torch.empty(fc1_w.shape, **f32)
     dfc2 = g2 if direct else torch.empty(fc2_w.shape, **f32)
-    ws2 = torch.empty(lib.srhip_attn_tail_mlp_workspace(n, hid) // 4, **f32)
-    _hip.check(lib.srhip_attn_tail_bwd_mlp(_p(ds), _p(avg), _p(mx), _p(s), _p(fc1_w.detach().contiguous()),
-                                           _p(fc2_w.detach().contiguous()), _p(davg), _p(dmax), _p(dfc1), _p(dfc2),
-                                           int(direct), _p(ws2), ws2.numel() * 4, n, c, hid, _stream()),
-               'attn_tail_bwd_mlp')
+    if not _TAIL_FUSED:                                        # A/B knob: the three separate entry points (10 launches)
+        ds = torch.empty(n, c, **f32)
+        ws = torch.empty(lib.srhip_attn_tail_bwd_workspace(n, h, w) // 4, **f32)
+        _hip.check(lib.srhip_attn_tail_bwd_spatial(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(w7.detach().contiguous()),
+                                                   _p(du), _p(ds), _p(dw7), int(g7 is not None), _p(ws), ws.numel() * 4, n, h, w, c,
+                                                   _stream()), 'attn_tail_bwd_spatial')
+        davg, dmax = torch.empty(n, c, **f32), torch.empty(n, c, **f32)
+        ws2 = torch.empty(lib.srhip_attn_tail_mlp_workspace(n, hid) // 4, **f32)
+        _hip.check(lib.srhip_attn_tail_bwd_mlp(_p(ds), _p(avg), _p(mx), _p(s), _p(fc1_w.detach().contiguous()),
+                                               _p(fc2_w.detach().contiguous()), _p(davg), _p(dmax), _p(dfc1), _p(dfc2), int(direct),
+                                               _p(ws2), ws2.numel() * 4, n, c, hid, _stream()), 'attn_tail_bwd_mlp')
+        _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg), _p(dmax), _p(arg), n, h, w, c, _stream()), 'attn_tail_bwd_channel')
+        return du, (None if direct else dfc1), (None if direct else dfc2), (None if g7 is not None else dw7), dwc, dbc
+    # spatial half (7x7 conv, per-pixel gate), channel half (sigmoid -> shared MLP) and the arg-max fix-up: one call
+    ws = torch.empty(lib.srhip_attn_tail_bwd_fused_workspace(n, h, w, hid) // 4, **f32)
+    _hip.check(lib.srhip_attn_tail_bwd(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
+                                       _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
+                                       _p(fc2_w.detach().contiguous()), _p(du), _p(dw7), int(g7 is not None), _p(dfc1), _p(dfc2),
+                                       int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd')
+    if g7 is not None:
+        dw7 = None
     if direct:
         dfc1 = dfc2 = None
-    _hip.check(lib.srhip_attn_tail_bwd_channel(_p(du), _p(davg), _p(dmax), _p(arg), n, h,
-                                               w, c, _stream()), 'attn_tail_bwd_channel')
     return du, dfc1, dfc2, dw7, dwc, dbc
 
 

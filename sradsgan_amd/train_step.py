@@ -117,6 +117,9 @@ class TrainStep:
         return ops.gp_penalty(grads)
 
     def _compute(self, imgs_lr, imgs_hr, alpha):
+        if (self.reuse_d_fake and self.use_gp and self.overlap_wgrad and self.overlap_d_step and self._wgrad_stream is not None
+                and self._d_stream is not None and os.environ.get('SRHIP_D_ONEWALK', '1') == '1'):
+            return self._compute_onewalk(imgs_lr, imgs_hr, alpha)
         if self.reuse_d_fake:
             return self._compute_shared(imgs_lr, imgs_hr, alpha)
         G, D, F = self.G, self.D, self.F
@@ -173,6 +176,96 @@ class TrainStep:
         if arena.flat_g.is_cuda and self.overlap_wgrad and self._wgrad_stream is not None:
             streams.append(self._wgrad_stream)                    # the weight-gradient kernels run there
         gs.start(which, arena.flat_g, after=streams)
+
+    def _compute_onewalk(self, imgs_lr, imgs_hr, alpha):
+        """The three-stream step with the discriminator's graph on the generated batch walked ONCE (default).
+
+        D(gen_hr) appears in both losses: loss_G carries -weight_gan * mean(D(gen_hr)) (sradsgan.py:847-852) and loss_D
+        +mean(D(gen_hr.detach())) (:877).  Both need the same data-gradient chain through D (and through its train-mode
+        BatchNorms) with upstream gradients that differ only by the constant factor -weight_gan, so the chain is walked once
+        with upstream +1: it yields d mean / d theta_D -- the fake term's contribution to D's gradients -- and
+        g = d mean / d gen_hr, which enters the generator's backward as (-weight_gan) * g at gen_hr.  (Walking it twice, as
+        _compute_shared does, costs a second data-gradient + BatchNorm-backward pass through D at 216 x 216 on the main
+        stream's critical path; the results differ by the rounding of one multiplication by weight_gan per element.)
+
+        Host order = dependency order of the three chains:
+          main : G forward, VGG(fake), D(gen), losses | walk of D(gen) [its weight gradients -> wgrad stream] | G backward
+          D    : (after the forward) D(real), D(interp) + first-order penalty backward | (after the walk) backward of the
+                 real and penalty terms, weight gradients in line -- all of it beside the generator's backward
+          wgrad: VGG(real) | fake-term weight gradients of D | the generator's weight gradients
+        D's gradient arena receives: fake term (main / wgrad stream), then real + penalty (D stream, after events) --
+        a fixed order, so the step stays deterministic."""
+        G, D, F = self.G, self.D, self.F
+        g_params, d_params = self.arena_G.params, self.arena_D.params
+        side, dside = self._wgrad_stream, self._d_stream
+        main = torch.cuda.current_stream()
+        self._set_d_grad(True)
+        self.arena_G.zero_grad()
+        self.arena_D.zero_grad()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            real_feat = F(imgs_hr)                               # depends on nothing the generator produces
+        imgs_hr.record_stream(side)
+        self._mark('start')
+        gen_hr = G(imgs_lr)
+        self._mark('G fwd done')
+        pixel = ops.l1_mean(gen_hr, imgs_hr)
+        fake_feat = F(gen_hr)
+        gen_in = gen_hr.detach().requires_grad_(True)            # the discriminator's graph hangs off its own leaf
+        stash = []
+        for bn in self._bns:
+            bn._stat_stash = stash
+        d_gen = D(gen_in)                                        # running-stat update #1
+        for bn in self._bns:
+            bn._stat_stash = None
+        main.wait_stream(side)
+        real_feat.record_stream(main)
+        content = ops.l1_mean(fake_feat, real_feat)
+        fake_term = ops.mean(d_gen)
+        loss_gan = -fake_term.detach()
+        loss_G_own = pixel + self.weight_content * content       # the part of loss_G whose graph is G + VGG
+        loss_G = loss_G_own.detach() + self.weight_gan * loss_gan
+        self._mark('fwd done (VGG, D(gen), losses)')
+        # ---- D stream: real pass, interpolate pass, first-order backward of the penalty ----
+        dside.wait_stream(main)
+        self._mark('D passes begin (D stream)', dside)
+        with torch.cuda.stream(dside):
+            real_term = -ops.mean(D(imgs_hr))                    # update #2 (real)
+            ops.replay_bn_update(stash)                          # update #3 (the fake pass that is not recomputed)
+            fake = gen_hr.detach()
+            gp = self.gradient_penalty(imgs_hr, fake, alpha)     # update #4
+            gp_term = (1.0 + self.lambda_gp) * gp                # :639 + :884-886 => 1 + lambda
+            loss_D = real_term.detach() + fake_term.detach() + self.lambda_gp * gp.detach()
+        self._mark('D passes + GP first order done (D stream)', dside)
+        for t in (gen_hr, gen_in, d_gen, alpha, fake_term):
+            t.record_stream(dside)
+        # ---- main: the one walk of D(gen) ----
+        torch.autograd.backward(fake_term, inputs=list(d_params) + [gen_in])
+        walked_main, walked_side = main.record_event(), side.record_event()
+        g_adv = gen_in.grad.mul_(-self.weight_gan)               # d(weight_gan * loss_gan) / d gen_hr
+        self._mark('D(gen) walked (main)')
+        # ---- D stream: backward of the real and penalty terms, after the fake term's contributions to D's arena ----
+        with torch.cuda.stream(dside):
+            dside.wait_event(walked_main)
+            dside.wait_event(walked_side)
+            with ops.direct_param_grads(None), ops.backward_scope(stop_at=(self._interp,)):
+                self._backward_terms([real_term, gp_term], d_params)
+        self._mark('D bwd of the real + penalty terms done (D stream)', dside)
+        # ---- main: the generator's backward ----
+        torch.autograd.backward([loss_G_own, gen_hr], grad_tensors=[None, g_adv], inputs=g_params)
+        self._exchange_start('G')
+        self._mark('G bwd done (main)')
+        self._mark('wgrads done (wgrad stream)', side)
+        main.wait_stream(dside)
+        main.wait_stream(side)
+        for t in (loss_D, gp):
+            t.record_stream(main)
+        self._exchange_start('D')
+        out = dict(loss_G=loss_G, loss_D=loss_D, pixel=pixel.detach(), content=content.detach(), loss_gan=loss_gan,
+                   gp=gp.detach(), gen_hr=fake)
+        if os.environ.get('SRHIP_STEP_DEBUG') == '1':
+            out['d_gen'] = d_gen.detach()
+        return out
 
     def _compute_shared(self, imgs_lr, imgs_hr, alpha):
         """Same arithmetic, one discriminator forward fewer: D(gen_hr) of the G step (:847) and
