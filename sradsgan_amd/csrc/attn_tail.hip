@@ -308,8 +308,8 @@ __global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, f
 // ---- B3: dy = m*dz + dpooled.x/C + [c == argc]*dpooled.y ; du = s*dy ; ds partial = sum_pix dy*u --- //
 // grid = (blocks_per_image, B); each block walks pixels of ONE image; 256 threads = 16 pixel lanes x 16
 // channel quads; dsp[b][blk][c] holds the block's partial of ds.
-// FOLD: the grid carries one extra block column; its block of image 0 does slam_conv7_wgrad_reduce_kernel's work (same
-// summation order), the other blocks of that column exit -- one launch less in the serial chain of every tail.
+// FOLD: the grid carries one extra block column that does slam_conv7_wgrad_reduce_kernel's work (same summation order per
+// tap, the 98 taps dealt over the column's blocks and waves) -- one launch less in the serial chain of every tail.
 template <bool FOLD>
 __global__ void tail_bwd_main_kernel(const float* __restrict__ dz, const float* __restrict__ u,
                                      const float* __restrict__ s, const float* __restrict__ m,
@@ -318,10 +318,9 @@ __global__ void tail_bwd_main_kernel(const float* __restrict__ dz, const float* 
                                      const float* __restrict__ w7part, float* __restrict__ dw7, int w7blk, int acc7) {
   __shared__ float4 red[256];
   const int b = blockIdx.y, nblk = FOLD ? gridDim.x - 1 : gridDim.x;
-  if (FOLD && blockIdx.x == nblk) {
-    if (b != 0) return;
+  if (FOLD && blockIdx.x == nblk) {                 // the extra column: image b's block sums taps 4 b + wave, + 4 n, ...
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int t = wv; t < 98; t += 4) {
+    for (int t = b * 4 + wv; t < 98; t += 4 * (int)gridDim.y) {
       float a = 0.f;
       for (int k = lane; k < w7blk; k += 64) a += w7part[(size_t)t * w7blk + k];
       a = wave_sum(a);
@@ -423,7 +422,8 @@ __global__ void clam_mlp_bwd_kernel(const float* __restrict__ ds, const float* _
   float dsv;
   if (nblk > 0) {
     dsv = 0.f;
-    for (int k = 0; k < nblk; ++k) dsv += ds[((size_t)b * nblk + k) * TC + c];
+#pragma unroll 16
+    for (int k = 0; k < nblk; ++k) dsv += ds[((size_t)b * nblk + k) * TC + c];      // (loads in flight together, adds in order)
   } else {
     dsv = ds[b * TC + c];
   }
