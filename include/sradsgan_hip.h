@@ -53,7 +53,8 @@ int srhip_abi_version(void);
  *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, 9 row-tap kernel without paired row tails, >= 10 register-staged
  *          kernel, >= 100 split-K block target of the row-tap kernel
  *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (0x100 / 0x200: timing only, wrong results;
- *          0x400: plain instead of non-temporal epilogue stores, correct results) */
+ *          0x400: plain instead of non-temporal epilogue stores, correct results)
+ *   key 4  1: the exact-fp32 SGAM kernels in every arithmetic mode (default: split-bf16 products outside SRHIP_MATH_FP32) */
 int srhip_debug_set(int key, int value);
 
 /* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *

@@ -58,6 +58,7 @@ extern int g_wgrad_cfg;
 extern int g_fast_dynlds;
 extern int g_fast_ablate;
 extern int g_conv_math;
+extern int g_sgam_cfg;
 }
 
 extern "C" {
@@ -78,6 +79,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 3) {
     g_fast_ablate = value;
+    return SRHIP_OK;
+  }
+  if (key == 4) {
+    g_sgam_cfg = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -553,6 +553,387 @@ __global__ __launch_bounds__(256) void ga_sgam_bwd_dkv_kernel(const float* __res
           make_float4(dvt[u][4 * gq], dvt[u][4 * gq + 1], dvt[u][4 * gq + 2], dvt[u][4 * gq + 3]);
 }
 
+// ================================================================================================ //
+// SGAM in split-bf16 (SRHIP_MATH_BF16X3 / SRHIP_MATH_HALF): the q.k energies, the soft-max statistics and every
+// accumulator stay fp32 (the energies feed an exp()); the four big products per 32 x 32 tile pair -- P.V, dP = dout.V^T,
+// dV = P^T.dout, dQ / dK = dS.K / dS^T.Q -- run as a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 like the
+// convolutions (fp32 MFMA: 172 instructions of 64 cycles per tile pair over the three kernels; here 12 fp32 + 126 bf16
+// of 32 cycles).  The register trick carries over: a C/D register file [16 rows of ONE column per lane] is directly the
+// B operand of a bf16 MFMA if the contraction index runs over the tile's rows in the order
+//     k slot 16 s + 8 h + j  <->  tile row ga_row(8 s + j, h)          (s = MFMA step, h = lane half, j = 0..7),
+// so the OTHER operand -- V^T, dout^T, K^T, Q^T -- is staged in LDS transposed with its 32 rows in exactly that order
+// (ga_pos), 8 bf16 "hi" resp. "lo" values per 16-byte fragment read.  Products contracted over channels (dP) read
+// row-major bf16 tiles.  hi = bf16(v), lo = bf16(v - hi), computed once per element when a tile is staged.
+// ================================================================================================ //
+typedef __bf16 ga_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ga_bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int GA_TS = 40;       // bf16 stride of a transposed tile row  [ch or d][32 slots]   (80 B: conflict-free b128 reads)
+constexpr int GA_RS = 72;       // bf16 stride of a row-major tile row   [32 rows][64 ch]      (144 B: conflict-free b128 reads)
+
+__device__ inline f32x16 ga_mfma16(const ga_bf16x8& a, const ga_bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// k slot of tile row `row` (0..31): the inverse of slot -> ga_row(8 s + j, h)
+__device__ __forceinline__ int ga_pos(int row) {
+  const int t = row & 15;
+  return (row & 16) + 8 * ((t >> 2) & 1) + (t & 3) + 4 * (t >> 3);
+}
+// registers 8 s .. 8 s + 7 of a C/D file as a split operand
+__device__ __forceinline__ void ga_split_regs(const f32x16& p, int s, ga_bf16x8& hi, ga_bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = p[8 * s + j];
+    const __bf16 hh = (__bf16)v;
+    hi[j] = hh;
+    lo[j] = (__bf16)(v - (float)hh);
+  }
+}
+__device__ __forceinline__ void ga_split_f4x2(const float4& a, const float4& b, ga_bf16x8& hi, ga_bf16x8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hh = (__bf16)v[j];
+    hi[j] = hh;
+    lo[j] = (__bf16)(v[j] - (float)hh);
+  }
+}
+// acc += A.B in split-bf16 (the small cross terms first)
+__device__ __forceinline__ f32x16 ga_mma3(const ga_bf16x8& ah, const ga_bf16x8& al, const ga_bf16x8& bh, const ga_bf16x8& bl, f32x16 c) {
+  c = ga_mfma16(al, bh, c);
+  c = ga_mfma16(ah, bl, c);
+  return ga_mfma16(ah, bh, c);
+}
+// staged wide tile [32][64] -> transposed split tiles th / tl [64][GA_TS] (rows in ga_pos order)
+__device__ __forceinline__ void ga_store_wide_T(const GaStage& s, __bf16* th, __bf16* tl, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i, pos = ga_pos(e >> 4), c0 = (e & 15) * 4;
+    const float v[4] = {s.w[i].x, s.w[i].y, s.w[i].z, s.w[i].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const __bf16 hh = (__bf16)v[c];
+      th[(c0 + c) * GA_TS + pos] = hh;
+      tl[(c0 + c) * GA_TS + pos] = (__bf16)(v[c] - (float)hh);
+    }
+  }
+}
+// staged wide tile [32][64] -> row-major split tiles rh / rl [32][GA_RS]
+__device__ __forceinline__ void ga_store_wide_R(const GaStage& s, __bf16* rh, __bf16* rl, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + 256 * i, row = e >> 4, c0 = (e & 15) * 4;
+    const float v[4] = {s.w[i].x, s.w[i].y, s.w[i].z, s.w[i].w};
+    ga_bf16x4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const __bf16 hh = (__bf16)v[c];
+      hi[c] = hh;
+      lo[c] = (__bf16)(v[c] - (float)hh);
+    }
+    *reinterpret_cast<ga_bf16x4*>(rh + row * GA_RS + c0) = hi;
+    *reinterpret_cast<ga_bf16x4*>(rl + row * GA_RS + c0) = lo;
+  }
+}
+// staged narrow tile [32][8]: fp32 copy nt (energies) and, when th != nullptr, transposed split tiles [8][GA_TS]
+__device__ __forceinline__ void ga_store_narrow(const GaStage& s, float* nt, __bf16* th, __bf16* tl, int tid) {
+  if (tid < 64) {
+    *reinterpret_cast<float4*>(nt + (tid >> 1) * GA_DK + (tid & 1) * 4) = s.n;
+    if (th != nullptr) {
+      const int pos = ga_pos(tid >> 1), d0 = (tid & 1) * 4;
+      const float v[4] = {s.n.x, s.n.y, s.n.z, s.n.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const __bf16 hh = (__bf16)v[c];
+        th[(d0 + c) * GA_TS + pos] = hh;
+        tl[(d0 + c) * GA_TS + pos] = (__bf16)(v[c] - (float)hh);
+      }
+    }
+  }
+}
+#define GA_FRAG(ptr) (*reinterpret_cast<const ga_bf16x8*>(ptr))
+
+__global__ __launch_bounds__(256) void ga_sgam_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, float* __restrict__ y,
+                                                             float* __restrict__ osave, float* __restrict__ lse, int hw) {
+  __shared__ __attribute__((aligned(16))) float kt[2][32 * GA_DK];
+  __shared__ __attribute__((aligned(16))) __bf16 vth[2][GA_C * GA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 vtl[2][GA_C * GA_TS];
+  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const size_t base = (size_t)img * hw;
+  const int qi = blockIdx.x * GA_PIX + wave * 32 + l31;
+  const bool qvalid = qi < hw;
+  const float4 qf = qvalid ? *reinterpret_cast<const float4*>(q + (base + qi) * GA_DK + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nt = (hw + 31) >> 5;
+  GaStage st_;
+  ga_stage_load(st_, v, k, base, 0, hw, tid, 1.f);
+  ga_store_wide_T(st_, vth[0], vtl[0], tid);
+  ga_store_narrow(st_, kt[0], nullptr, nullptr, tid);
+  __syncthreads();
+  f32x16 ot[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[u][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    const int b = t & 1, k0 = t * 32;
+    if (t + 1 < nt) ga_stage_load(st_, v, k, base, k0 + 32, hw, tid, 1.f);
+    f32x16 p = ga_scores_t(kt[b], qf, h, l31);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (k0 + ga_row(r, h) >= hw) p[r] = -INFINITY;
+      tmax = fmaxf(tmax, p[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(m, tmax);
+    const float alpha = expf(m - mnew);
+    m = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = expf(p[r] - mnew);
+      psum += p[r];
+    }
+    l = l * alpha + psum;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[u][r] *= alpha;
+    // O^T[ch][query] += sum_key V^T[ch][key] P[key][query]: A = transposed V fragment, B = registers 8 s .. 8 s + 7 of P
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ga_bf16x8 ph, pl;
+      ga_split_regs(p, s, ph, pl);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int off = (32 * u + l31) * GA_TS + 16 * s + 8 * h;
+        ot[u] = ga_mma3(GA_FRAG(vth[b] + off), GA_FRAG(vtl[b] + off), ph, pl, ot[u]);
+      }
+    }
+    if (t + 1 < nt) {
+      ga_store_wide_T(st_, vth[b ^ 1], vtl[b ^ 1], tid);
+      ga_store_narrow(st_, kt[b ^ 1], nullptr, nullptr, tid);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (!qvalid) return;
+  const float inv = 1.f / l, g = gamma[0];
+  if (h == 0) lse[base + qi] = m + logf(l);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const size_t idx = (base + qi) * GA_C + 32 * u + 8 * gq + 4 * h;
+      const float4 o4 = make_float4(ot[u][4 * gq] * inv, ot[u][4 * gq + 1] * inv, ot[u][4 * gq + 2] * inv, ot[u][4 * gq + 3] * inv);
+      const float4 x4 = *reinterpret_cast<const float4*>(x + idx);
+      *reinterpret_cast<float4*>(osave + idx) = o4;
+      *reinterpret_cast<float4*>(y + idx) = make_float4(g * o4.x + x4.x, g * o4.y + x4.y, g * o4.z + x4.z, g * o4.w + x4.w);
+    }
+}
+
+// query-tile owner, split-bf16: dq[query][d] = sum_key dS[query][key] k[key][d]
+__global__ __launch_bounds__(256) void ga_sgam_bwd_dq_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ dy,
+                                                                const float* __restrict__ lse, const float* __restrict__ rowdot,
+                                                                const float* __restrict__ gamma, float* __restrict__ dq, int hw) {
+  __shared__ __attribute__((aligned(16))) float kt[2][32 * GA_DK];
+  __shared__ __attribute__((aligned(16))) __bf16 kth[2][GA_DK * GA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 ktl[2][GA_DK * GA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 vrh[2][32 * GA_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 vrl[2][32 * GA_RS];
+  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const size_t base = (size_t)img * hw;
+  const int qi = blockIdx.x * GA_PIX + wave * 32 + l31;
+  const bool qvalid = qi < hw;
+  const float g = gamma[0];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 qf = qvalid ? *reinterpret_cast<const float4*>(q + (base + qi) * GA_DK + 4 * h) : z4;
+  const float lq = qvalid ? lse[base + qi] : 0.f;
+  const float dq_ = qvalid ? g * rowdot[base + qi] : 0.f;
+  ga_bf16x8 doh[4], dol[4];                              // dout[query][16 c + 8 h + j] = gamma * dy, split once
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float4 a = qvalid ? *reinterpret_cast<const float4*>(dy + (base + qi) * GA_C + 16 * c + 8 * h) : z4;
+    float4 b = qvalid ? *reinterpret_cast<const float4*>(dy + (base + qi) * GA_C + 16 * c + 8 * h + 4) : z4;
+    a.x *= g; a.y *= g; a.z *= g; a.w *= g;
+    b.x *= g; b.y *= g; b.z *= g; b.w *= g;
+    ga_split_f4x2(a, b, doh[c], dol[c]);
+  }
+  const int nt = (hw + 31) >> 5;
+  GaStage st_;
+  ga_stage_load(st_, v, k, base, 0, hw, tid, 1.f);
+  ga_store_wide_R(st_, vrh[0], vrl[0], tid);
+  ga_store_narrow(st_, kt[0], kth[0], ktl[0], tid);
+  __syncthreads();
+  f32x16 dqt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    const int b = t & 1, k0 = t * 32;
+    if (t + 1 < nt) ga_stage_load(st_, v, k, base, k0 + 32, hw, tid, 1.f);
+    f32x16 p = ga_scores_t(kt[b], qf, h, l31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = (k0 + ga_row(r, h) < hw) ? expf(p[r] - lq) : 0.f;
+    // dP^T[key][query] = sum_ch V[key][ch] dout[query][ch]: A = row-major V fragment of key l31, B = this lane's dout
+    f32x16 dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = l31 * GA_RS + 16 * c + 8 * h;
+      dpt = ga_mma3(GA_FRAG(vrh[b] + off), GA_FRAG(vrl[b] + off), doh[c], dol[c], dpt);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = p[r] * (dpt[r] - dq_);       // dS^T
+    // dQ^T[d][query] += sum_key K^T[d][key] dS^T[key][query]: rows d >= 8 of the tile are don't-care
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ga_bf16x8 sh, sl;
+      ga_split_regs(p, s, sh, sl);
+      const int off = (l31 & 7) * GA_TS + 16 * s + 8 * h;
+      dqt = ga_mma3(GA_FRAG(kth[b] + off), GA_FRAG(ktl[b] + off), sh, sl, dqt);
+    }
+    if (t + 1 < nt) {
+      ga_store_wide_R(st_, vrh[b ^ 1], vrl[b ^ 1], tid);
+      ga_store_narrow(st_, kt[b ^ 1], kth[b ^ 1], ktl[b ^ 1], tid);
+    }
+    __syncthreads();
+  }
+  if (qvalid) *reinterpret_cast<float4*>(dq + (base + qi) * GA_DK + 4 * h) = make_float4(dqt[0], dqt[1], dqt[2], dqt[3]);
+}
+
+// key-tile owner, split-bf16: dv[key][ch] = sum_query P dout, dk[key][d] = sum_query dS q
+__global__ __launch_bounds__(256) void ga_sgam_bwd_dkv_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ dy,
+                                                                 const float* __restrict__ lse, const float* __restrict__ rowdot,
+                                                                 const float* __restrict__ gamma, float* __restrict__ dk,
+                                                                 float* __restrict__ dv, int hw) {
+  __shared__ __attribute__((aligned(16))) float qt[2][32 * GA_DK];
+  __shared__ __attribute__((aligned(16))) __bf16 qth[2][GA_DK * GA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 qtl[2][GA_DK * GA_TS];
+  __shared__ __attribute__((aligned(16))) __bf16 drh[2][32 * GA_RS];     // dout tile, row-major (dP)
+  __shared__ __attribute__((aligned(16))) __bf16 drl[2][32 * GA_RS];
+  __shared__ __attribute__((aligned(16))) __bf16 dth[2][GA_C * GA_TS];   // dout tile, transposed (dV)
+  __shared__ __attribute__((aligned(16))) __bf16 dtl[2][GA_C * GA_TS];
+  __shared__ __attribute__((aligned(16))) float lt[2][32];
+  __shared__ __attribute__((aligned(16))) float dt[2][32];
+  const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const size_t base = (size_t)img * hw;
+  const int kj = blockIdx.x * GA_PIX + wave * 32 + l31;
+  const bool kvalid = kj < hw;
+  const float g = gamma[0];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 kf = kvalid ? *reinterpret_cast<const float4*>(k + (base + kj) * GA_DK + 4 * h) : z4;
+  ga_bf16x8 vfh[4], vfl[4];                              // V[key][16 c + 8 h + j], split once
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 a = kvalid ? *reinterpret_cast<const float4*>(v + (base + kj) * GA_C + 16 * c + 8 * h) : z4;
+    const float4 b = kvalid ? *reinterpret_cast<const float4*>(v + (base + kj) * GA_C + 16 * c + 8 * h + 4) : z4;
+    ga_split_f4x2(a, b, vfh[c], vfl[c]);
+  }
+  const int nt = (hw + 31) >> 5;
+  GaStage st_;
+  float sl = 0.f;                                        // threads 64..95: lse, 96..127: D = gamma * rowdot
+  auto load = [&](int r0) {
+    ga_stage_load(st_, dy, q, base, r0, hw, tid, g);
+    if (tid >= 64 && tid < 96) {
+      const int row = r0 + tid - 64;
+      sl = row < hw ? lse[base + row] : INFINITY;      // exp(s - inf) = 0: padded queries carry no probability
+    } else if (tid >= 96 && tid < 128) {
+      const int row = r0 + tid - 96;
+      sl = row < hw ? g * rowdot[base + row] : 0.f;
+    }
+  };
+  auto store = [&](int b) {
+    ga_store_wide_R(st_, drh[b], drl[b], tid);
+    ga_store_wide_T(st_, dth[b], dtl[b], tid);
+    ga_store_narrow(st_, qt[b], qth[b], qtl[b], tid);
+    if (tid >= 64 && tid < 96) lt[b][tid - 64] = sl;
+    else if (tid >= 96 && tid < 128) dt[b][tid - 96] = sl;
+  };
+  load(0);
+  store(0);
+  __syncthreads();
+  f32x16 dvt[2], dkt;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dvt[0][r] = 0.f;
+    dvt[1][r] = 0.f;
+    dkt[r] = 0.f;
+  }
+  for (int t = 0; t < nt; ++t) {
+    const int b = t & 1;
+    if (t + 1 < nt) load(t * 32 + 32);
+    // S[query][key]: A = Q row of query l31 (d = 4h + s), B = this lane's key
+    const float4 q4 = *reinterpret_cast<const float4*>(qt[b] + l31 * GA_DK + 4 * h);
+    f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = 0.f;
+    p = ga_mfma(q4.x, kf.x, p);
+    p = ga_mfma(q4.y, kf.y, p);
+    p = ga_mfma(q4.z, kf.z, p);
+    p = ga_mfma(q4.w, kf.w, p);
+    float dd[16];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {                     // rows 4gq + e of this lane are queries 8gq + 4h + e
+      const float4 l4 = *reinterpret_cast<const float4*>(lt[b] + 8 * gq + 4 * h);
+      const float4 d4 = *reinterpret_cast<const float4*>(dt[b] + 8 * gq + 4 * h);
+      p[4 * gq] = expf(p[4 * gq] - l4.x);
+      p[4 * gq + 1] = expf(p[4 * gq + 1] - l4.y);
+      p[4 * gq + 2] = expf(p[4 * gq + 2] - l4.z);
+      p[4 * gq + 3] = expf(p[4 * gq + 3] - l4.w);
+      dd[4 * gq] = d4.x; dd[4 * gq + 1] = d4.y; dd[4 * gq + 2] = d4.z; dd[4 * gq + 3] = d4.w;
+    }
+    // dP[query][key] = sum_ch dout[query][ch] V[key][ch]: A = row-major dout fragment of query l31, B = this lane's V row
+    f32x16 dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int off = l31 * GA_RS + 16 * c + 8 * h;
+      dp = ga_mma3(GA_FRAG(drh[b] + off), GA_FRAG(drl[b] + off), vfh[c], vfl[c], dp);
+    }
+    // dV^T[ch][key] += sum_query dout^T[ch][query] P[query][key]: A = transposed dout fragment, B = registers of P
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ga_bf16x8 ph, pl;
+      ga_split_regs(p, s, ph, pl);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int off = (32 * u + l31) * GA_TS + 16 * s + 8 * h;
+        dvt[u] = ga_mma3(GA_FRAG(dth[b] + off), GA_FRAG(dtl[b] + off), ph, pl, dvt[u]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - dd[r]);      // dS
+    // dK^T[d][key] += sum_query Q^T[d][query] dS[query][key]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ga_bf16x8 sh, sl2;
+      ga_split_regs(p, s, sh, sl2);
+      const int off = (l31 & 7) * GA_TS + 16 * s + 8 * h;
+      dkt = ga_mma3(GA_FRAG(qth[b] + off), GA_FRAG(qtl[b] + off), sh, sl2, dkt);
+    }
+    if (t + 1 < nt) store(b ^ 1);
+    __syncthreads();
+  }
+  if (!kvalid) return;
+  *reinterpret_cast<float4*>(dk + (base + kj) * GA_DK + 4 * h) = make_float4(dkt[0], dkt[1], dkt[2], dkt[3]);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      *reinterpret_cast<float4*>(dv + (base + kj) * GA_C + 32 * u + 8 * gq + 4 * h) =
+          make_float4(dvt[u][4 * gq], dvt[u][4 * gq + 1], dvt[u][4 * gq + 2], dvt[u][4 * gq + 3]);
+}
+
+int g_sgam_cfg = 0;   // srhip_debug_set(4, v): 1 = the exact-fp32 SGAM kernels in every arithmetic mode (A/B and tests)
+extern int g_conv_math;
+static inline bool ga_split_math() { return g_conv_math >= 1 && g_sgam_cfg != 1; }
+
 static inline int ga_nsplit(int hw) { return cdiv(hw, GA_PIX); }
 static inline int ga_prep_blocks(long npix) {
   long b = (npix + 15) / 16;
@@ -616,7 +997,10 @@ int srhip_sgam_flash_fwd(const float* q, const float* k, const float* v, const f
   SRHIP_REQUIRE(n > 0 && hw > 0, "sgam_flash_fwd: empty input");
   SRHIP_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)x | (uintptr_t)y | (uintptr_t)o) & 15) == 0,
                 "sgam_flash_fwd: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(ga_sgam_fwd_kernel, dim3(cdiv(hw, GA_PIX), n), dim3(256), 0, as_stream(stream), q, k, v, x, gamma, y, o, lse, hw);
+  if (ga_split_math())
+    hipLaunchKernelGGL(ga_sgam_fwd_x3_kernel, dim3(cdiv(hw, GA_PIX), n), dim3(256), 0, as_stream(stream), q, k, v, x, gamma, y, o, lse, hw);
+  else
+    hipLaunchKernelGGL(ga_sgam_fwd_kernel, dim3(cdiv(hw, GA_PIX), n), dim3(256), 0, as_stream(stream), q, k, v, x, gamma, y, o, lse, hw);
   return check_launch("sgam_flash_fwd");
 }
 
@@ -645,8 +1029,13 @@ int srhip_sgam_flash_bwd(const float* dy, const float* q, const float* k, const 
   hipLaunchKernelGGL(ga_sgam_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, dy, o, rowdot, dgpart, npix);
   if (dgamma) hipLaunchKernelGGL(ga_sum_small_kernel, dim3(1), dim3(64), 0, st, dgpart, pb, dgamma, accumulate_dgamma);
   const dim3 grid(cdiv(hw, GA_PIX), n);
-  hipLaunchKernelGGL(ga_sgam_bwd_dq_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dq, hw);
-  hipLaunchKernelGGL(ga_sgam_bwd_dkv_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dk_, dv, hw);
+  if (ga_split_math()) {
+    hipLaunchKernelGGL(ga_sgam_bwd_dq_x3_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dq, hw);
+    hipLaunchKernelGGL(ga_sgam_bwd_dkv_x3_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dk_, dv, hw);
+  } else {
+    hipLaunchKernelGGL(ga_sgam_bwd_dq_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dq, hw);
+    hipLaunchKernelGGL(ga_sgam_bwd_dkv_kernel, grid, dim3(256), 0, st, q, k, v, dy, lse, rowdot, gamma, dk_, dv, hw);
+  }
   return check_launch("sgam_flash_bwd");
 }
 

@@ -9,6 +9,7 @@ timeout 900 python bench.py > $E/bench_n1.log 2>&1; tail -1 $E/bench_n1.log > $E
 timeout 600 python bench.py --no-cpu-baseline --conv-math fp32 2>&1 | tail -1 > $E/bench_n1_fp32.json; cut -c1-200 $E/bench_n1_fp32.json
 timeout 600 python bench.py --no-cpu-baseline --conv-math half 2>&1 | tail -1 > $E/bench_n1_half.json; cut -c1-200 $E/bench_n1_half.json
 timeout 600 python bench.py --workload infer 2>&1 | tail -1 > $E/bench_infer.json; cut -c1-260 $E/bench_infer.json
+for W in srgan sragan edsr; do timeout 600 python bench.py --workload $W --steps 20 --warmup 5 2>&1 | tail -1 > $E/bench_$W.json; cut -c1-200 $E/bench_$W.json; done
 timeout 900 python bench.py --workload chain 2>&1 | tail -1 > $E/bench_chain_half.json; cut -c1-300 $E/bench_chain_half.json
 timeout 900 python bench.py --workload chain --conv-math bf16x3 2>&1 | tail -1 > $E/bench_chain_bf16x3.json; cut -c1-300 $E/bench_chain_bf16x3.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $E/bench_n1_rccl_single_rank.json; cut -c1-200 $E/bench_n1_rccl_single_rank.json
