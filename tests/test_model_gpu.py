@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import sradsgan_ref as O
-from tests.parity_util import build_pair, rel_err, train_parity
+from tests.parity_util import ZERO_GRAD_KEYS, build_pair, rel_err, train_parity
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -41,6 +41,13 @@ def _module_case(golden, tag, hip_mod, ora_mod, x, grad_keys):
     _close(O.digest(xh.grad), g['dx'], msg='dx vs reference')
     hp, op = dict(hip_mod.named_parameters()), dict(ora_mod.named_parameters())
     for k in grad_keys:
+        if k.endswith(ZERO_GRAD_KEYS):
+            # identically zero in exact arithmetic (SGAM's key bias: soft-max shift invariance): every platform sees only the
+            # roundoff of a cancelling sum over all pixels, so the yardstick is the sibling weight's gradient, not the value
+            scale = float(op[k.replace('bias', 'weight')].grad.abs().max())
+            err = float(hp[k].grad.cpu().abs().max())
+            assert err <= TOL * scale, '%s: |roundoff| %.3e vs weight-gradient scale %.3e' % (k, err, scale)
+            continue
         _close(hp[k].grad.cpu(), op[k].grad, msg=k + ' vs oracle')
         _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], msg=k + ' vs reference')
 
