@@ -650,6 +650,9 @@ __device__ __forceinline__ void ga_store_narrow(const GaStage& s, float* nt, __b
     }
   }
 }
+// exp() of the split-bf16 kernels: v_exp_f32(x * log2(e)) (two instructions; libm's expf is ~15 and the three kernels call it
+// 16 times per lane and tile).  Error <= |x| * 2^-24 relative, i.e. < 1e-6 wherever the probability is not negligible.
+__device__ __forceinline__ float ga_exp(float x) { return __expf(x); }
 #define GA_FRAG(ptr) (*reinterpret_cast<const ga_bf16x8*>(ptr))
 
 __global__ __launch_bounds__(256) void ga_sgam_fwd_x3_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -688,12 +691,12 @@ __global__ __launch_bounds__(256) void ga_sgam_fwd_x3_kernel(const float* __rest
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mnew = fmaxf(m, tmax);
-    const float alpha = expf(m - mnew);
+    const float alpha = ga_exp(m - mnew);
     m = mnew;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = expf(p[r] - mnew);
+      p[r] = ga_exp(p[r] - mnew);
       psum += p[r];
     }
     l = l * alpha + psum;
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(256) void ga_sgam_bwd_dq_x3_kernel(const float* __r
     if (t + 1 < nt) ga_stage_load(st_, v, k, base, k0 + 32, hw, tid, 1.f);
     f32x16 p = ga_scores_t(kt[b], qf, h, l31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = (k0 + ga_row(r, h) < hw) ? expf(p[r] - lq) : 0.f;
+    for (int r = 0; r < 16; ++r) p[r] = (k0 + ga_row(r, h) < hw) ? ga_exp(p[r] - lq) : 0.f;
     // dP^T[key][query] = sum_ch V[key][ch] dout[query][ch]: A = row-major V fragment of key l31, B = this lane's dout
     f32x16 dpt;
 #pragma unroll
@@ -881,10 +884,10 @@ __global__ __launch_bounds__(256) void ga_sgam_bwd_dkv_x3_kernel(const float* __
     for (int gq = 0; gq < 4; ++gq) {                     // rows 4gq + e of this lane are queries 8gq + 4h + e
       const float4 l4 = *reinterpret_cast<const float4*>(lt[b] + 8 * gq + 4 * h);
       const float4 d4 = *reinterpret_cast<const float4*>(dt[b] + 8 * gq + 4 * h);
-      p[4 * gq] = expf(p[4 * gq] - l4.x);
-      p[4 * gq + 1] = expf(p[4 * gq + 1] - l4.y);
-      p[4 * gq + 2] = expf(p[4 * gq + 2] - l4.z);
-      p[4 * gq + 3] = expf(p[4 * gq + 3] - l4.w);
+      p[4 * gq] = ga_exp(p[4 * gq] - l4.x);
+      p[4 * gq + 1] = ga_exp(p[4 * gq + 1] - l4.y);
+      p[4 * gq + 2] = ga_exp(p[4 * gq + 2] - l4.z);
+      p[4 * gq + 3] = ga_exp(p[4 * gq + 3] - l4.w);
       dd[4 * gq] = d4.x; dd[4 * gq + 1] = d4.y; dd[4 * gq + 2] = d4.z; dd[4 * gq + 3] = d4.w;
     }
     // dP[query][key] = sum_ch dout[query][ch] V[key][ch]: A = row-major dout fragment of query l31, B = this lane's V row
