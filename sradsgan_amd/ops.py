@@ -1206,15 +1206,6 @@ def batch_norm_act(x, bn, slope=None):
                                                 _p(bn.running_mean), _p(bn.running_var), _p(y), n * h * w, c, float(bn.eps),
                                                 float(slope or 0.0), int(slope is not None), _stream()), 'bn_eval_fwd')
         return y
-    defer = getattr(bn, '_stat_defer', None)
-    if defer is not None:
-        # The caller runs this forward pass EARLIER than the reference's position of its running-statistics update (TrainStep:
-        # D(real) beside the generator's forward): the kernel leaves the running buffers alone and the caller replays the
-        # update from the batch statistics at the reference's position (replay_bn_update)
-        y = _BNTrainFwd.apply(x, bn.weight, bn.bias, None, None, bn.eps, bn.momentum, slope)
-        x_, y_, g_, mean, invstd, b_ = y.grad_fn.saved_tensors
-        defer.append((bn, mean, invstd, x.numel() // x.shape[1]))
-        return y
     y = _BNTrainFwd.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, slope)
     with torch.no_grad():
         bn.num_batches_tracked += 1

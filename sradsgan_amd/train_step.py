@@ -207,28 +207,6 @@ class TrainStep:
             real_feat = F(imgs_hr)                               # depends on nothing the generator produces
         imgs_hr.record_stream(side)
         self._mark('start')
-        real_early = os.environ.get('SRHIP_D_REAL_EARLY', '1') == '1'
-        real_term = real_stash = real_done = None
-        if real_early:
-            # D(real) and the backward of its loss term need only the real batch and D's weights: run them on the D stream
-            # beside the generator's FORWARD, where the GPU has room (one busy stream), instead of beside its backward (three).
-            # BatchNorm's running statistics must still be updated in the reference's order (#1 D(gen), #2 D(real), ...), so this
-            # early pass leaves the running buffers alone and the update is replayed from its batch statistics further down.
-            dside.wait_stream(main)                              # arenas zeroed
-            with torch.cuda.stream(dside):
-                real_stash = []
-                for bn in self._bns:
-                    bn._stat_defer = real_stash
-                try:
-                    real_term = -ops.mean(D(imgs_hr))
-                finally:
-                    for bn in self._bns:
-                        bn._stat_defer = None
-                with ops.direct_param_grads(None):
-                    self._backward_terms([real_term], d_params)
-                real_done = dside.record_event()
-            imgs_hr.record_stream(dside)
-            self._mark('D(real) forward + backward done (D stream)', dside)
         gen_hr = G(imgs_lr)
         self._mark('G fwd done')
         pixel = ops.l1_mean(gen_hr, imgs_hr)
@@ -252,10 +230,7 @@ class TrainStep:
         dside.wait_stream(main)
         self._mark('D passes begin (D stream)', dside)
         with torch.cuda.stream(dside):
-            if real_early:
-                ops.replay_bn_update(real_stash)                 # update #2 (real), at the reference's position
-            else:
-                real_term = -ops.mean(D(imgs_hr))                # update #2 (real)
+            real_term = -ops.mean(D(imgs_hr))                    # update #2 (real)
             ops.replay_bn_update(stash)                          # update #3 (the fake pass that is not recomputed)
             fake = gen_hr.detach()
             gp = self.gradient_penalty(imgs_hr, fake, alpha)     # update #4
@@ -265,9 +240,6 @@ class TrainStep:
         for t in (gen_hr, gen_in, d_gen, alpha, fake_term):
             t.record_stream(dside)
         # ---- main: the one walk of D(gen) ----
-        if real_early:                                           # D's arena: the real term's contributions first
-            main.wait_event(real_done)
-            side.wait_event(real_done)
         torch.autograd.backward(fake_term, inputs=list(d_params) + [gen_in])
         walked_main, walked_side = main.record_event(), side.record_event()
         g_adv = gen_in.grad.mul_(-self.weight_gan)               # d(weight_gan * loss_gan) / d gen_hr
@@ -277,7 +249,7 @@ class TrainStep:
             dside.wait_event(walked_main)
             dside.wait_event(walked_side)
             with ops.direct_param_grads(None), ops.backward_scope(stop_at=(self._interp,)):
-                self._backward_terms([gp_term] if real_early else [real_term, gp_term], d_params)
+                self._backward_terms([real_term, gp_term], d_params)
         self._mark('D bwd of the real + penalty terms done (D stream)', dside)
         # ---- main: the generator's backward ----
         torch.autograd.backward([loss_G_own, gen_hr], grad_tensors=[None, g_adv], inputs=g_params)

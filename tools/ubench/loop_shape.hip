@@ -110,5 +110,10 @@ int main() {
   run<24, 8, 24, 17, 200>("Winograd F(2x2,3x3), 32 tiles x BN=64: whole K chunk", 2.25, 150, 1, out, wsrc);
   run<12, 4, 4, 2, 14>("direct, 2 taps per B tile read (fewer fragment bytes)", 1.0, 48, 3, out, wsrc);
   run<24, 4, 12, 4, 28>("direct, 2 taps per barrier", 1.0, 64, 2, out, wsrc);
+  run<6, 2, 6, 1, 10>("direct patch loop, BN=64 (Cout = 64 convs, shipping): per tap", 1.0, 36, 3, out, wsrc);
+  run<12, 2, 12, 2, 20>("direct patch loop, BN=64, two taps per barrier", 1.0, 48, 3, out, wsrc);
+  run<18, 2, 18, 3, 30>("direct patch loop, BN=64, three taps per barrier", 1.0, 48, 3, out, wsrc);
+  run<4, 4, 4, 2, 8>("half mode (one product), BN=128: per tap", 3.0, 48, 3, out, wsrc);
+  run<12, 4, 12, 6, 24>("half mode (one product), BN=128: three taps per barrier", 3.0, 72, 2, out, wsrc);
   return 0;
 }
