@@ -1,8 +1,9 @@
 // Global attention block of GAB_UP (SRADSGAN/model/sradsgan.py:153-213), C = 64, NHWC fp32:
 //   CGAM  (:178-213, light=False)  E = X^T X [64x64], A = softmax(rowmax(E) - E), y = gamma * (X A^T) + x
 //   SGAM  (:153-176)               q,k [N][8], v [N][64]; att = softmax_j(q_i . k_j); y = gamma * (att v) + x
-// Everything is exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32 = an fmaf chain): the channel energies are
-// sums over thousands of pixels that feed an exp(), so the split-bf16 products of the conv kernels are not used here.
+// CGAM and SGAM's q.k energies / soft-max are exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32 = an fmaf chain): the
+// energies are sums that feed an exp().  SGAM's four big products per tile pair (P.V, dP, dV, dQ / dK) follow the conv
+// arithmetic mode: split-bf16 (a*b ~= ah*bh + ah*bl + al*bh, fp32 accumulate) outside SRHIP_MATH_FP32 -- second half of this file.
 //
 // SGAM is flash-style: the N x N energy / attention matrices never exist in HBM (N = 2916 at x4, 11664 at x2: the
 // reference materialises 34 MB resp. 544 MB per image, twice).  A wave owns 32 queries and walks the keys in tiles of
