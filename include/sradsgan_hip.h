@@ -39,13 +39,16 @@ extern "C" {
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
+/* `to_stream` waits for everything enqueued on `from_stream` so far (event record + stream wait, events from an internal
+ * ring; legal under stream capture: it forks `to_stream` into the capture).  Host-side helper, no kernel.  */
+int srhip_stream_fork(void* from_stream, void* to_stream);
 /* ABI 2: fast packed weights carry a second, pre-split bf16 section (srhip_packed_elems doubled for them);
  * srhip_set_conv_math / srhip_get_conv_math added.
  * ABI 3: srhip_cgam_*, srhip_sgam_flash_*, loss reductions (srhip_l1_mean_*, srhip_mean_*, srhip_gp_norm_penalty_*),
  * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added;
  *        fast packed weights carry a third (fp16) section, SRHIP_MATH_HALF.
  * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed).
- * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace) added (no existing entry point changed). */
+ * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace), srhip_stream_fork added (no existing entry point changed). */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,

@@ -15,6 +15,7 @@ _vp, _i, _f, _l, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_l
 SIGNATURES = {
     'srhip_last_error': (ctypes.c_char_p, []),
     'srhip_abi_version': (_i, []),
+    'srhip_stream_fork': (_i, [_vp, _vp]),
     'srhip_debug_set': (_i, [_i, _i]),
     'srhip_set_conv_math': (_i, [_i]),
     'srhip_get_conv_math': (_i, []),

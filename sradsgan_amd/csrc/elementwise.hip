@@ -232,6 +232,32 @@ extern "C" {
 const char* srhip_last_error(void) { return g_err; }
 int srhip_abi_version(void) { return 5; }
 
+// `to` waits for everything enqueued on `from` so far: one event record + one stream wait through a small ring of
+// timing-less events (an event can be re-recorded once the wait that used it has been ENQUEUED: hipStreamWaitEvent
+// captures the record that is current at the call).  The weight-gradient kernels are forked to their stream ~150 times per
+// training step; from Python that is torch.cuda.Event() + record + wait + a stream context per launch.
+int srhip_stream_fork(void* from_stream, void* to_stream) {
+  constexpr int RING = 64;
+  static hipEvent_t ring[RING];
+  static int created = 0, next = 0;
+  if (from_stream == to_stream) return SRHIP_OK;
+  if (!created) {
+    for (int i = 0; i < RING; ++i)
+      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) {
+        set_error("stream_fork: hipEventCreateWithFlags failed");
+        return SRHIP_ERR_LAUNCH;
+      }
+    created = 1;
+  }
+  hipEvent_t ev = ring[next];
+  next = (next + 1) % RING;
+  if (hipEventRecord(ev, as_stream(from_stream)) != hipSuccess || hipStreamWaitEvent(as_stream(to_stream), ev, 0) != hipSuccess) {
+    set_error("stream_fork: %s", hipGetErrorString(hipGetLastError()));
+    return SRHIP_ERR_LAUNCH;
+  }
+  return SRHIP_OK;
+}
+
 int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream) {
   SRHIP_REQUIRE(dy && y && dx && count >= 0, "lrelu_bwd: bad argument");
   if (count == 0) return SRHIP_OK;

@@ -29,6 +29,7 @@ class _State:
     wgrad_stream = None             # side HIP stream for weight-gradient kernels (direct_param_grads mode only)
     skip_ids = frozenset()          # id()s of parameters whose gradients the current backward must not produce
     stop_ids = frozenset()          # data_ptr()s of tensors the current backward must not propagate into
+    capturing = False               # a stream capture is being recorded (TrainStep._capture): side-stream forks go through torch events
 
 
 _state = _State()
@@ -337,15 +338,42 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, s
     return dx
 
 
-def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=None, xchanscale=None, out=None):
+_SIDE_WS = {}
+_FORK_C = os.environ.get('SRHIP_FORK_C', '1') == '1'      # A/B knob: 0 = fork the side stream through torch events + a stream context
+
+
+def _side_workspace(nbytes, device, stream):
+    """One persistent split-K workspace per side stream: the kernels of one stream run in order, so they can share it, and a
+    buffer that is never freed needs no record_stream (a per-call buffer allocated on the launching stream and used on the
+    side stream would)."""
+    key = (device.index, stream.cuda_stream)
+    ws = _SIDE_WS.get(key)
+    need = (max(int(nbytes), 4) + 3) // 4
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            ws.record_stream(stream)                     # kernels already enqueued may still use the old buffer
+        ws = _SIDE_WS[key] = torch.empty(max(need, 1 << 20), device=device, dtype=torch.float32)
+    return ws
+
+
+def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=None, xchanscale=None, out=None, on_stream=None):
     """(dw [OIHW], db [Cout] or None): the bias gradient comes out of the same kernel pass.
-    out=(dw_buf, db_buf or None): accumulate into these buffers instead (dw_buf += dw, db_buf += db)."""
+    out=(dw_buf, db_buf or None): accumulate into these buffers instead (dw_buf += dw, db_buf += db).
+    on_stream: launch on this torch stream (already ordered behind the operands' producers by the caller) instead of the
+    current one, with that stream's persistent workspace."""
     _require_gpu(x, 'conv2d_wgrad')
     x, dy = nhwc(x), nhwc(dy)
     n, cin, h, wd = x.shape
     cout, _, kh, kw = w_shape
     lib = _hip.lib()
     nbytes = lib.srhip_conv2d_wgrad_workspace(n, h, wd, cin, cout, kh, kw, stride, pad)
+    if on_stream is not None:
+        ws = _side_workspace(nbytes, x.device, on_stream)
+        dw, db = out
+        _hip.check(lib.srhip_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(xrowscale), _p(xchanscale), 1, _p(ws),
+                                          ws.numel() * 4, n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout,
+                                          ctypes.c_void_p(on_stream.cuda_stream)), 'conv2d_wgrad')
+        return dw, db
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=x.device, dtype=torch.float32)
     if out is None:
         dw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
@@ -376,10 +404,16 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
         # run them on a side stream so the partially filled last wave of each data-gradient kernel and of
         # each wgrad kernel overlap.  Same-parameter accumulations stay ordered (one side stream).
         x, dy = nhwc(x), nhwc(dy)
-        main = torch.cuda.current_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+        if _state.capturing or not _FORK_C:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
+        else:
+            # one C call forks the side stream behind the current one (event ring inside the library) and the kernel is
+            # launched on it by handle: no torch Event, no stream context, no per-call workspace (~150 launches per step)
+            _hip.check(_hip.lib().srhip_stream_fork(_stream(), ctypes.c_void_p(side.cuda_stream)), 'stream_fork')
+            conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb), on_stream=side)
         for t in (x, dy, xrowscale, xchanscale):
             if t is not None:
                 t.record_stream(side)

@@ -461,13 +461,13 @@ class TrainStep:
         dump = os.environ.get('SRHIP_GRAPH_DUMP')
         if dump:
             self._graph.enable_debug_mode()
-        self._capturing = True
+        self._capturing = ops._state.capturing = True
         try:
             # same arithmetic and the same per-stream program order as the eager path
             with torch.cuda.graph(self._graph):
                 self._out = self._run_compute(self._static['lr'], self._static['hr'], self._static['alpha'])
         finally:
-            self._capturing = False
+            self._capturing = ops._state.capturing = False
         if dump:
             self._graph.debug_dump(dump)
 

@@ -113,6 +113,10 @@ int main() {
   run<6, 2, 6, 1, 10>("direct patch loop, BN=64 (Cout = 64 convs, shipping): per tap", 1.0, 36, 3, out, wsrc);
   run<12, 2, 12, 2, 20>("direct patch loop, BN=64, two taps per barrier", 1.0, 48, 3, out, wsrc);
   run<18, 2, 18, 3, 30>("direct patch loop, BN=64, three taps per barrier", 1.0, 48, 3, out, wsrc);
+  run<18, 6, 26, 3, 170>("row-tap wgrad loop (shipping): per 16-pixel chunk", 1.0, 40, 3, out, wsrc);
+  run<18, 6, 26, 3, 60>("row-tap wgrad loop with a third of the VALU work", 1.0, 40, 3, out, wsrc);
+  run<18, 6, 12, 3, 60>("row-tap wgrad loop, transposed 16-byte fragment reads, a third of the VALU", 1.0, 40, 3, out, wsrc);
+  run<36, 6, 52, 6, 340>("row-tap wgrad loop, two chunks per barrier", 1.0, 64, 2, out, wsrc);
   run<4, 4, 4, 2, 8>("half mode (one product), BN=128: per tap", 3.0, 48, 3, out, wsrc);
   run<12, 4, 12, 6, 24>("half mode (one product), BN=128: three taps per barrier", 3.0, 72, 2, out, wsrc);
   return 0;
