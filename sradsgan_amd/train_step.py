@@ -6,8 +6,9 @@ Structure (MI355X-first, not the reference's call order):
               THREE HIP streams -- main (forward passes, data gradients), weight gradients, discriminator passes -- that
               fork and join through events.  Eager by default; with use_graph=True the whole three-stream compute part is
               captured once into ONE hipGraph (the side streams fork from and join the capturing stream, so their kernels
-              become parallel branches of the graph) and replayed per iteration: the host enqueues a step in a few
-              milliseconds instead of ~40 (the x8 / x9 steps are launch-bound in eager mode).
+              become parallel branches of the graph) and replayed per iteration: the host enqueues a step in ~15 ms
+              instead of 30 - 45 -- but ROCm 7.0's graph executor replays multi-branch graphs slower than the eager
+              streams run them (99 vs 63 ms), so eager stays the default.
   exchange  = in-place bucketed all-reduce of the G and D gradient arenas over RCCL (only with
               world_size > 1; sradsgan_amd/dp.py GradSync) on its own HIP stream: G's arena is sent as soon as
               the generator's backward is enqueued and travels under the whole discriminator step, D's after
@@ -23,7 +24,11 @@ Differences from the reference that do not change results (DESIGN.md "restructur
     gradients the reference computes and then throws away (:857 -> :865) are never computed;
   * the gradient penalty's double backward runs once with weight (1 + lambda_gp) instead of twice
     (once inside gradient_penalty() :639, once inside loss_D.backward() :886) -- same sum;
-  * losses stay on the device; nothing calls .item() inside the step (the reference syncs 4x, :898).
+  * losses stay on the device; nothing calls .item() inside the step (the reference syncs 4x, :898);
+  * D(gen_hr) feeds both losses (-weight_gan * mean in loss_G :847-852, +mean in loss_D :877): its graph is walked ONCE with
+    upstream +1, which yields the fake term's share of D's gradients and g = d mean / d gen_hr; the generator's backward takes
+    (-weight_gan) * g at gen_hr (_compute_onewalk; differs from two walks by the rounding of one multiplication per element);
+  * the discriminator's real and penalty terms are backpropagated on the D stream beside the generator's backward, not after it.
 """
 import ctypes
 import os
