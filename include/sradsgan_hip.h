@@ -52,6 +52,7 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
+ *          24 the patch kernel with 64-wide N tiles for every Cout (experiment: twice the blocks, -8 %),
  *          1..8 fixed tile shapes of the register-staged kernel
  *   key 1  wgrad: 0 heuristic, 1/2 N tile 64/128, 5 256-wide tiles, 7 no row-tap kernel, 9 row-tap kernel without paired row tails, >= 10 register-staged
  *          kernel, >= 100 split-K block target of the row-tap kernel

@@ -2036,12 +2036,12 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
                     (!actmask || ((uintptr_t)actmask & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   // stride-1 3x3 in split-bf16: the patch kernel (g_fast_cfg 21 turns it off, -2 forces it at any size)
   bool patch_to_dma = false;             // g_fast_cfg 23: every launch the patch kernel would take goes to the (bit-identical) DMA kernel
-  if (g_conv_math >= 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && (g_fast_cfg < 1 || g_fast_cfg == 23) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+  if (g_conv_math >= 1 && g_fast_cfg != 20 && g_fast_cfg != 21 && (g_fast_cfg < 1 || g_fast_cfg == 23 || g_fast_cfg == 24) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       !(eflags & (SRHIP_EPI_CHANSCALE | SRHIP_EPI_ROWSCALE)) && !g.accumulate) {
     PatchGeom pg;
     if (plan_patch(g, &pg)) {
       const int nbm = g.N * pg.tiles_h * pg.tiles_w;
-      const bool wide = g.K >= 128;
+      const bool wide = g.K >= 128 && g_fast_cfg != 24;   // 24: experiment, 64-wide N tiles for every Cout (twice the blocks)
       const int nbn = cdiv(g.K, wide ? 128 : 64);
       if (g_fast_cfg == 23) {
         patch_to_dma = (long)nbm * nbn >= 256;
@@ -2082,7 +2082,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       }
     }
   }
-  if (g_fast_cfg != 20 && (g_fast_cfg < 1 || g_fast_cfg == 23) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
+  if (g_fast_cfg != 20 && (g_fast_cfg < 1 || g_fast_cfg == 23 || g_fast_cfg == 24) && !(g.flags & 0x300) && g.K >= 64 && al16 &&
       (!(eflags & SRHIP_EPI_CHANSCALE) || ((uintptr_t)chanscale & 15) == 0)) {
     const int nbm = cdiv(g.M, 128);
     const bool force = g_fast_cfg == -1 || patch_to_dma;   // tests: take the DMA kernels at any problem size
