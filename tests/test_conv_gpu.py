@@ -400,3 +400,29 @@ def test_single_destination_channel_small_grid(case):
         finally:
             _hip.lib().srhip_debug_set(0, 0)
         assert _rel(y22, ref) < 2e-5
+
+
+def test_stream_fork_orders_the_side_stream_behind_the_current_one():
+    """srhip_stream_fork(from, to): everything enqueued on `to` afterwards runs behind what `from` holds at the call.  A long
+    chain of dependent kernels on stream A produces a buffer; stream B, forked behind A by the C helper (no torch event, no
+    stream context), copies it: the copy must see the final values -- repeated 200 times so that the library's event ring wraps."""
+    import ctypes
+    from sradsgan_amd import _hip
+    lib = _hip.lib()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 22, device=DEV)
+    out = torch.empty_like(x)
+    torch.cuda.synchronize()
+    for it in range(200):
+        with torch.cuda.stream(a):
+            for _ in range(6):
+                x.add_(1.0)                                   # 6 dependent passes over 16 MB
+        _hip.check(lib.srhip_stream_fork(ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream)), 'stream_fork')
+        with torch.cuda.stream(b):
+            out.copy_(x)
+        _hip.check(lib.srhip_stream_fork(ctypes.c_void_p(b.cuda_stream), ctypes.c_void_p(a.cuda_stream)), 'stream_fork')
+        if it % 50 == 49:
+            torch.cuda.synchronize()
+            assert float(out.min()) == float(out.max()) == 6.0 * (it + 1), (it, float(out.min()), float(out.max()))
+    torch.cuda.synchronize()
+    assert float(out.min()) == float(out.max()) == 1200.0
