@@ -410,7 +410,7 @@ def test_stream_fork_orders_the_side_stream_behind_the_current_one():
     from sradsgan_amd import _hip
     lib = _hip.lib()
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
-    x = torch.zeros(1 << 22, device=DEV)
+    x = torch.zeros(1 << 22, device='cuda:0')
     out = torch.empty_like(x)
     torch.cuda.synchronize()
     for it in range(200):
