@@ -68,6 +68,22 @@ class ParamArena:
         return True
 
 
+def share_unique_id(make_id, rank, world, generation):
+    """The communicator id as every rank must pass it to srhip_dp_init: rank 0 draws it (make_id() -> bytes) and publishes it
+    in torch.distributed's rendezvous store under a key that carries the communicator's generation -- every rank creates its
+    communicators in the same order, so the key of a destroyed communicator is never read again --; the other ranks block in
+    store.get until it is there.  No collective, no second process group."""
+    if world <= 1:
+        return make_id()
+    store = dist.distributed_c10d._get_default_store()
+    key = 'srhip_dp_unique_id/%d' % generation
+    if rank == 0:
+        raw = make_id()
+        store.set(key, raw)
+        return raw
+    return bytes(store.get(key))
+
+
 class GradSync:
     """The per-iteration gradient exchange and its ordering: `start(tag, flat)` launches the bucketed in-place
     all-reduce(SUM) of a gradient arena as soon as its producers are enqueued, `finish(tag)` makes the consumer (the Adam
@@ -130,19 +146,13 @@ class GradSync:
         world = dist.get_world_size() if dist.is_initialized() else 1
         if lib.srhip_dp_world() == 0:
             nbytes = lib.srhip_dp_id_bytes()
-            buf = ctypes.create_string_buffer(nbytes)
-            if world > 1:
-                store = dist.distributed_c10d._get_default_store()
-                key = 'srhip_dp_unique_id/%d' % _COMM_GENERATION      # every rank creates its communicators in the same order
-                if rank == 0:
-                    _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
-                    store.set(key, bytes(buf.raw))
-                else:
-                    raw = store.get(key)                              # blocks until rank 0 has published it
-                    buf = ctypes.create_string_buffer(bytes(raw), nbytes)
-            else:
+
+            def make_id():
+                buf = ctypes.create_string_buffer(nbytes)
                 _hip.check(lib.srhip_dp_unique_id(buf), 'dp_unique_id')
-            _hip.check(lib.srhip_dp_init(buf, rank, world), 'dp_init')
+                return bytes(buf.raw)
+            raw = share_unique_id(make_id, rank, world, _COMM_GENERATION)
+            _hip.check(lib.srhip_dp_init(ctypes.create_string_buffer(raw, nbytes), rank, world), 'dp_init')
             _COMM_GENERATION += 1
         if lib.srhip_dp_world() != world:
             raise RuntimeError('GradSync: RCCL communicator has %d ranks, torch.distributed %d' % (lib.srhip_dp_world(), world))

@@ -95,6 +95,33 @@ def test_exchange_ordering_world2(tmp_path):
     assert [open(os.path.join(str(tmp_path), 'ord%d' % r)).read() for r in range(2)] == ['1', '1']
 
 
+def _id_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sradsgan_amd.dp import share_unique_id
+    import time
+    ids = []
+    for generation in range(2):                              # a second communicator must not pick up the first one's id
+        if rank == 0:
+            time.sleep(0.3)                                  # the other rank is already blocked in store.get
+        ids.append(share_unique_id(lambda: os.urandom(128), rank, world, generation))
+    mine = torch.tensor([list(i) for i in ids], dtype=torch.uint8)
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok = torch.equal(both[0], both[1]) and ids[0] != ids[1] and all(len(i) == 128 for i in ids)
+    open(os.path.join(out_dir, 'id%d' % rank), 'w').write('1' if ok else '0')
+    dist.destroy_process_group()
+
+
+def test_communicator_id_hand_off_world2(tmp_path):
+    """dp.share_unique_id: how the RCCL communicator id travels from rank 0 to the others (rendezvous store, generation-keyed) --
+    the one part of GradSync.init_rccl that only runs with more than one rank."""
+    port = _free_port()
+    mp.spawn(_id_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), 'id%d' % r)).read() for r in range(2)] == ['1', '1']
+
+
 def test_train_step_drives_the_exchange_in_that_order():
     """TrainStep's own call sequence, checked without a GPU: _exchange_start / _update call GradSync.start('G'),
     start('D'), finish('G'), finish('D') in this order (a recording stand-in replaces the arenas and kernels)."""
