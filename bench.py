@@ -211,7 +211,7 @@ def _time_isolated(fn, iters=20):
     return tot / iters
 
 
-def time_dominant_kernel(device, batch, sustained=True):
+def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     """HIP-event timing, on the stream they are launched on, of the two kernels that dominate the step at the
     bench shape [batch,64,54,54] (36 RAB blocks): the conv fprop/dgrad kernel on RAB conv1 (3x3, 64->256, +bias
     +LeakyReLU) -> 'roofline', and the wgrad kernel on the same conv -> second return value."""
@@ -235,10 +235,23 @@ def time_dominant_kernel(device, batch, sustained=True):
           'half': 'conv_patch_kernel<128,run-time epilogue,fp16 single product>'}[math]
     kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>',
           'half': 'wgrad_rowtap_kernel<128,64,bf16 single product>'}[math]
+    # The step launches the weight gradients of consecutive RABs in pairs (srhip_conv2d_wgrad_multi): the
+    # dominant weight-gradient launch therefore processes TWO convolutions, and `roofline_wgrad` times exactly that launch
+    # (main kernel + its two reduces) with twice the algorithmic FLOPs; the single-convolution launch of rounds 1-2 is timed
+    # next to it (`single_conv_launch_ms`, `single_conv_frac`).
+    group = max(1, min(4, int(os.environ.get('SRHIP_WGRAD_GROUP', '2')))) if math != 'fp32' else 1
+    x2 = torch.randn_like(x)
+    dy2 = torch.randn_like(dy)
+    gw = [torch.zeros(256, 64, 3, 3, device=device) for _ in range(group)]
+    gb = [torch.zeros(256, device=device) for _ in range(group)]
+    items = [((x, x2)[i % 2], (dy, dy2)[i % 2], gw[i], gb[i], 1, 1) for i in range(group)]
+    single_wgrad = lambda: ops.conv2d_wgrad_raw(x, dy, (256, 64, 3, 3), 1, 1, True)
+    wgrad_fn = (lambda: ops.conv2d_wgrad_multi_raw(items)) if group > 1 else single_wgrad
+    kw_label = (kw + ' x%d convolutions per launch + %d reduces' % (group, group)) if group > 1 else (kw + ' + reduce')
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
-            ('wgrad', kw + ' + reduce: 3x3 64->256 @54x54 wgrad (RAB conv1)',
-             lambda: ops.conv2d_wgrad_raw(x, dy, (256, 64, 3, 3), 1, 1, True))):
+            ('wgrad', kw_label + ': 3x3 64->256 @54x54 wgrad (RAB conv1)', wgrad_fn)):
+        flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9 * (group if key == 'wgrad' else 1)
         # Two short HIP-event measurements, both reported (`achieved` itself comes from the sustained loop below; with
         # --no-sustained from the LONGER of these two): back-to-back launches
         # (sustained clocks; but the drain of one launch's non-temporal stores overlaps the next launch: bf16x3 kernels
@@ -292,6 +305,11 @@ def time_dominant_kernel(device, batch, sustained=True):
         rec['launches_timed'] = n
         rec['achieved'] = round(flops / (sus * 1e-3) / 1e12, 2)
         rec['frac'] = round(rec['achieved'] / peak, 4)
+        if key == 'wgrad' and group > 1 and with_single:         # (not under the profiler: keeps its per-kernel averages to the grouped launch)
+            one = _time_launches(single_wgrad, 200)
+            rec['convolutions_per_launch'] = group
+            rec['single_conv_launch_ms'] = round(one, 4)
+            rec['single_conv_frac'] = round(flops / group / (one * 1e-3) / 1e12 / peak, 4)
         out.append(rec)
     return out[0], out[1]
 
@@ -642,7 +660,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     if args.roofline_only:
-        r0, r1 = time_dominant_kernel(device, args.batch, not args.no_sustained)
+        r0, r1 = time_dominant_kernel(device, args.batch, not args.no_sustained, with_single=False)
         print(json.dumps({'roofline': r0, 'roofline_wgrad': r1}), flush=True)
         return
     if args.workload == 'infer':

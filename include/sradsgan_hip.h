@@ -48,7 +48,8 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
  * srhip_dp_* (RCCL gradient exchange), srhip_cbam_* / srhip_sigmoid_* (discriminator attention primitives) added;
  *        fast packed weights carry a third (fp16) section, SRHIP_MATH_HALF.
  * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed).
- * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace), srhip_stream_fork added (no existing entry point changed). */
+ * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace), srhip_stream_fork, srhip_conv2d_wgrad_multi (+ _ok)
+ *        added (no existing entry point changed). */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
@@ -133,6 +134,16 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* d
                        size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw,
                        int stride, int pad, int ldx, int ldy, void* stream);
 
+/* GROUPED weight gradient (round 3): nprob = 2..4 convolutions of the SAME shape (stride-1 pad-1 3x3, Cin % 64 == 0, split-bf16 or
+ * half arithmetic, enough pixels: srhip_conv2d_wgrad_multi_ok returns the largest group size) in ONE main launch.  The chip wants one full wave of blocks whatever the number
+ * of convolutions behind it, so each problem runs with 1 / nprob of the splits: split-K partial traffic, the write burst at the
+ * end of the kernel and the reduce shrink by nprob.  x / dy / dw / db are HOST arrays of nprob device pointers (db or db[i] NULL:
+ * no bias gradient); workspace as for srhip_conv2d_wgrad of one problem.  The step pairs the weight gradients of consecutive
+ * RABs (model/sradsgan.py:222-223 of blocks i and i+1): nothing reads them before the optimiser.                     */
+int srhip_conv2d_wgrad_multi_ok(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);   /* largest nprob (2..4), 0: not served */
+int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const* dy, float* const* dw, float* const* db,
+                             int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                             int kh, int kw, int stride, int pad, int ldx, int ldy, void* stream);
 /* The same for a conv with a fused LeakyReLU (sradsgan.py:476: D's 3 -> 64 head conv), from the gradient at the ACTIVATED
  * output: dy * (y > 0 ? 1 : slope) is formed while dy is read, so no lrelu-backward pass is needed when only the weight and
  * bias gradients of the layer are wanted.  srhip_conv2d_wgrad_act_ok says whether the shape is served (3-channel 3x3

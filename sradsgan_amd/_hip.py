@@ -32,6 +32,8 @@ SIGNATURES = {
     'srhip_conv2d_dgrad': (_i, [_vp] * 5 + [_f] + [_i] * 13 + [_vp]),
     'srhip_conv2d_wgrad_workspace': (_sz, [_i] * 9),
     'srhip_conv2d_wgrad_can_accumulate': (_i, [_i] * 4),
+    'srhip_conv2d_wgrad_multi_ok': (_i, [_i] * 9),
+    'srhip_conv2d_wgrad_multi': (_i, [_i] + [_vp] * 4 + [_i, _vp, _sz] + [_i] * 11 + [_vp]),
     'srhip_conv2d_wgrad_act_ok': (_i, [_i] * 9),
     'srhip_conv2d_wgrad_act': (_i, [_vp] * 3 + [_f] + [_vp] * 3 + [_sz] + [_i] * 11 + [_vp]),
     'srhip_conv2d_wgrad': (_i, [_vp] * 6 + [_i, _vp, _sz] + [_i] * 11 + [_vp]),

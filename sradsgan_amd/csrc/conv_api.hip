@@ -202,6 +202,23 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, co
   return colsum_launch(dy, db, static_cast<char*>(workspace) + wbytes, (long)n * ho * wo, cout, ldy, as_stream(stream));
 }
 
+/* nprob (2..4) weight gradients of the SAME shape (stride-1 3x3, row-tap eligible, split-bf16 / half arithmetic) in one launch:
+ * x[i], dy[i] -> dw[i] (+ db[i] when db and db[i] are non-NULL), written or accumulated into.  See WgradBatch in conv_fast.hip. */
+int srhip_conv2d_wgrad_multi_ok(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  if (n <= 0 || h <= 0 || w <= 0 || !fast_wgrad_ok(cin, cout, kh, kw)) return 0;
+  return fast_wgrad_multi_max(n, h, w, cin, cout, kh, kw, stride, pad);
+}
+int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const* dy, float* const* dw, float* const* db,
+                             int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                             int kh, int kw, int stride, int pad, int ldx, int ldy, void* stream) {
+  SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad_multi: null pointer table");
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, "conv2d_wgrad_multi: bad geometry");
+  SRHIP_REQUIRE(srhip_conv2d_wgrad_multi_ok(n, h, w, cin, cout, kh, kw, stride, pad) >= nprob,
+                "conv2d_wgrad_multi: shape / size not served for %d problems (srhip_conv2d_wgrad_multi_ok)", nprob);
+  return fast_conv2d_wgrad_multi(nprob, x, dy, dw, db, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad,
+                                 ldx, ldy, as_stream(stream));
+}
+
 /* Weight + bias gradient of a conv whose output went through a fused LeakyReLU, from the gradient at the ACTIVATED output:
  * dy_eff = dy * (y > 0 ? 1 : slope) is formed while dy is read (3-channel 3x3 stride-1 head convs at >= 65536 pixels only). */
 int srhip_conv2d_wgrad_act(const float* x, const float* dy, const float* y, float slope, float* dw, float* db, void* workspace,

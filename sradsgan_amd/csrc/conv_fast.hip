@@ -1523,10 +1523,36 @@ __global__ __launch_bounds__(256) void fast_wgrad_dma_kernel(const float* __rest
 // LDS: 3-slot ring of [16 px][BM] dy + [20 px][64] x (fp32, lane-linear LDS-DMA images); same split-K partial
 // layout, reduce kernel and XCD mapping as the other wgrad kernels.
 // ================================================================================================ //
+// GROUPED launches (round 3): up to 4 weight gradients of the SAME shape in one launch.  The chip wants one full wave of blocks
+// (768) whatever the number of convolutions behind it, so G problems run with nsplit / G splits each: the split-K partial
+// tiles (the 2 x 76 MB per convolution that made the single launch move 2.5 x its algorithmic bytes), the end-of-kernel
+// write burst and the reduce shrink by G, and every block's K loop gets G times longer.  Blocks [p * bpp, (p + 1) * bpp)
+// serve problem p (bpp % 8 == 0 keeps a block's XCD = its split lane).
+struct WgradBatch {
+  const float* x[4];
+  const float* dy[4];
+  float* partial[4];
+  float* bias_partial[4];
+  int nprob, bpp;
+};
+
 template <int BM, int CIS, bool SPLIT = true>     // SPLIT false: one bf16 product per multiply (SRHIP_MATH_HALF)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_rowtap_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    float* __restrict__ bias_partial, WgradGeom g, int nseg, int chunks_per_split, int tail_rem) {
+    const float* __restrict__ x_, const float* __restrict__ dy_, float* __restrict__ partial_,
+    float* __restrict__ bias_partial_, WgradGeom g, int nseg, int chunks_per_split, int tail_rem, WgradBatch bt) {
+  const float* x = x_;
+  const float* dy = dy_;
+  float* partial = partial_;
+  float* bias_partial = bias_partial_;
+  int bid0 = blockIdx.x;
+  if (bt.nprob > 1) {
+    const int prob = __builtin_amdgcn_readfirstlane((int)blockIdx.x / bt.bpp);
+    bid0 = (int)blockIdx.x - prob * bt.bpp;
+    x = bt.x[prob];
+    dy = bt.dy[prob];
+    partial = bt.partial[prob];
+    bias_partial = bt.bias_partial[prob];
+  }
   // tail_rem > 0 ("paired tails", rows of 16 q + tail_rem pixels with tail_rem <= 8): the chunks are enumerated per PAIR of
   // image rows -- q full 16-pixel segments of row A, q of row B, then ONE chunk that holds both rows' tails: MFMA K index
   // k < 8 is pixel 16 q + k of row A, k >= 8 pixel 16 q + (k - 8) of row B (slots past the tail carry dy = 0).  Each half
@@ -1557,7 +1583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   int tile_n, tile_m, split;                        // XCD-aware order, as in fast_wgrad_kernel
   {
     const int tps = ntm * ntn;
-    int bid = blockIdx.x;
+    int bid = bid0;
     if (g.nsplit % 8 == 0) {
       const int j = bid >> 3;
       split = (j / tps) * 8 + (bid & 7);
@@ -2328,16 +2354,16 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
     const int cps = cdiv(nchunks_rt, p.nsplit);
     if (rowtap == 1 && g_conv_math == 2)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
     else if (rowtap == 1)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
     else if (g_conv_math == 2)
       hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
     else
       hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem);
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
   } else if (p.bm == 256 && p.bn == 64)
     SRHIP_LW(256, 64, 4, 1);
   else if (p.bm == 64 && p.bn == 256)
@@ -2361,6 +2387,92 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
     hipLaunchKernelGGL(fast_wgrad_reduce_kernel<4>, dim3(cdiv(total, 64)), dim3(256), 0, st, partial, bias_partial, dw,
                        db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
   return check_launch("fast_wgrad_reduce");
+}
+
+// ---- grouped row-tap weight gradient: nprob (2..4) convolutions of one shape, one main launch + nprob reduces ----
+int fast_wgrad_multi_ok(int cin, int cout, int kh, int kw, int stride, int pad) {
+  return g_conv_math >= 1 ? rowtap_ok(cin, cout, kh, kw, stride, pad) : 0;
+}
+static int multi_nsplit(const FastWgradPlan& p, int nprob) {
+  int ns = p.nsplit / nprob;
+  ns = ns / 8 * 8;
+  return ns < 8 ? 0 : ns;
+}
+// largest group size (2..4) a problem of this geometry can share a launch with, 0: none (shape, arithmetic mode or too few chunks)
+int fast_wgrad_multi_max(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  const int rowtap = fast_wgrad_multi_ok(cin, cout, kh, kw, stride, pad);
+  if (!rowtap) return 0;
+  FastWgradPlan p = plan_fast_wgrad((long)n * h * w, cout, kh * kw * cin, rowtap);
+  for (int k = 4; k >= 2; --k)
+    if (multi_nsplit(p, k) > 0) return k;
+  return 0;
+}
+size_t fast_conv2d_wgrad_multi_workspace(int nprob, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
+  return fast_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);     // nprob * (nsplit / nprob) partial sets
+}
+int fast_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const* dy, float* const* dw, float* const* db,
+                            int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                            int kh, int kw, int stride, int pad, int ldx, int ldy, hipStream_t st) {
+  SRHIP_REQUIRE(nprob >= 2 && nprob <= 4, "conv2d_wgrad_multi: 2..4 problems per launch");
+  const int rowtap = fast_wgrad_multi_ok(cin, cout, kh, kw, stride, pad);
+  SRHIP_REQUIRE(rowtap != 0, "conv2d_wgrad_multi: shape / arithmetic mode not served by the row-tap kernel");
+  WgradGeom g;
+  g.N = n; g.H = h; g.W = w; g.C = cin; g.ldx = ldx;
+  g.Ho = h; g.Wo = w;                                     // stride 1, pad 1, 3 x 3
+  g.K = cout; g.ldy = ldy; g.KH = kh; g.KW = kw; g.stride = stride; g.pad = pad;
+  const long P = (long)n * g.Ho * g.Wo;
+  SRHIP_REQUIRE(P < (1L << 31) - 64, "conv2d_wgrad_multi: pixel count overflows int32");
+  g.P = (int)P; g.Ktot = kh * kw * cin;
+  SRHIP_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad_multi: row strides % 4 == 0");
+  SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.x_bytes) && bytes_ok(P, ldy, cout, &g.dy_bytes), "conv2d_wgrad_multi: tensor >= 2 GiB");
+  FastWgradPlan p = plan_fast_wgrad(P, cout, g.Ktot, rowtap);
+  const int ns = multi_nsplit(p, nprob);
+  SRHIP_REQUIRE(ns > 0, "conv2d_wgrad_multi: problem too small to share a launch (use srhip_conv2d_wgrad)");
+  const int nseg = cdiv(g.Wo, 16);
+  const int rem = g.Wo & 15;
+  const int tail_rem = (rem > 0 && rem <= 8 && g.Wo >= 16 && g.Ho >= 2 && g_wgrad_cfg != 9) ? rem : 0;
+  const int nchunks_rt = tail_rem ? ((g.N * g.Ho + 1) / 2) * (2 * (g.Wo / 16) + 1) : g.N * g.Ho * nseg;
+  const int cps = cdiv(nchunks_rt, ns);
+  g.nsplit = ns; g.chunks_per_split = cps;
+  const size_t per = (size_t)ns * ((size_t)cout * g.Ktot + cout);
+  SRHIP_REQUIRE(workspace && workspace_bytes >= per * nprob * sizeof(float), "conv2d_wgrad_multi: workspace too small");
+  WgradBatch bt;
+  bt.nprob = nprob;
+  const int tiles = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn);
+  bt.bpp = tiles * ns;
+  bool any_bias = false;
+  for (int i = 0; i < 4; ++i) {
+    const int k = i < nprob ? i : 0;
+    SRHIP_REQUIRE(x[k] && dy[k] && dw[k] && ((((uintptr_t)x[k]) | ((uintptr_t)dy[k])) & 15) == 0, "conv2d_wgrad_multi: null / unaligned tensor");
+    float* part = static_cast<float*>(workspace) + per * k;
+    bt.x[i] = x[k];
+    bt.dy[i] = dy[k];
+    bt.partial[i] = part;
+    bt.bias_partial[i] = (db && db[k]) ? part + (size_t)ns * cout * g.Ktot : nullptr;
+    any_bias = any_bias || bt.bias_partial[i] != nullptr;
+  }
+  const int blocks = bt.bpp * nprob;
+  if (rowtap == 1 && g_conv_math == 2)
+    hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
+  else if (rowtap == 1)
+    hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
+  else if (g_conv_math == 2)
+    hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
+  else
+    hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
+  int rc = check_launch("fast_wgrad_multi");
+  if (rc) return rc;
+  for (int k = 0; k < nprob; ++k) {
+    float* dbk = db ? db[k] : nullptr;
+    const long total = (long)cout * g.Ktot + (dbk ? cout : 0);
+    if (ns >= 64)
+      hipLaunchKernelGGL(fast_wgrad_reduce_kernel<16>, dim3(cdiv(total, 64)), dim3(1024), 0, st, bt.partial[k], bt.bias_partial[k], dw[k], dbk, ns, cout, cin,
+                         kh * kw, g.Ktot, accumulate);
+    else
+      hipLaunchKernelGGL(fast_wgrad_reduce_kernel<4>, dim3(cdiv(total, 64)), dim3(256), 0, st, bt.partial[k], bt.bias_partial[k], dw[k], dbk, ns, cout, cin,
+                         kh * kw, g.Ktot, accumulate);
+  }
+  return check_launch("fast_wgrad_multi_reduce");
 }
 
 }  // namespace srhip

@@ -56,6 +56,13 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
                       int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,
                       hipStream_t st);
 
+int fast_wgrad_multi_ok(int cin, int cout, int kh, int kw, int stride, int pad);
+int fast_wgrad_multi_max(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
+size_t fast_conv2d_wgrad_multi_workspace(int nprob, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
+int fast_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const* dy, float* const* dw, float* const* db,
+                            int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                            int kh, int kw, int stride, int pad, int ldx, int ldy, hipStream_t st);
+
 // column sums (elementwise.hip), used for the bias gradient on the generic path
 size_t colsum_workspace_bytes(long rows, int c);
 int colsum_launch(const float* dy, float* db, void* workspace, long rows, int c, int ld, hipStream_t st);

@@ -30,6 +30,8 @@ class _State:
     skip_ids = frozenset()          # id()s of parameters whose gradients the current backward must not produce
     stop_ids = frozenset()          # data_ptr()s of tensors the current backward must not propagate into
     capturing = False               # a stream capture is being recorded (TrainStep._capture): side-stream forks go through torch events
+    wgrad_group = 1                 # weight gradients of one shape launched together (srhip_conv2d_wgrad_multi); 1 = off
+    pending = None                  # shape key -> [(x, dy, gw, gb, stride, pad)] waiting for partners (direct_param_grads mode)
 
 
 _state = _State()
@@ -70,18 +72,20 @@ def no_param_grads():
 
 
 @contextlib.contextmanager
-def direct_param_grads(side_stream=None):
+def direct_param_grads(side_stream=None, group=1):
     """Inside this context the fused backward kernels ACCUMULATE parameter gradients straight into the
     parameters' existing .grad buffers (the gradient arena of dp.ParamArena) and hand autograd None for
     them: one wgrad launch per conv instead of wgrad + one `grad += new` launch per parameter
     (~600 tiny launches per step).  Only valid when every such parameter already owns a dense .grad
     and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
-    prev = (_state.direct_grads, _state.wgrad_stream)
+    prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending)
     _state.direct_grads, _state.wgrad_stream = True, side_stream
+    _state.wgrad_group, _state.pending = (group if side_stream is not None else 1), {}
     try:
         yield
+        flush_pending_wgrads()
     finally:
-        _state.direct_grads, _state.wgrad_stream = prev
+        _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending = prev
 
 
 def _grad_slot(p):
@@ -388,6 +392,76 @@ def conv2d_wgrad_raw(x, dy, w_shape, stride, pad, with_bias=False, xrowscale=Non
     return dw, db
 
 
+def _fork_side(side, handles=None):
+    """The side stream waits for everything enqueued so far on the current stream (and on the streams whose raw handles are
+    given: the producers of operands that were queued for a grouped launch)."""
+    hs = {_stream().value}
+    if handles:
+        hs.update(handles)
+    hs.discard(side.cuda_stream)
+    for h in hs:
+        if _state.capturing or not _FORK_C:
+            side.wait_stream(torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream())
+        else:
+            _hip.check(_hip.lib().srhip_stream_fork(ctypes.c_void_p(h), ctypes.c_void_p(side.cuda_stream)), 'stream_fork')
+
+
+def conv2d_wgrad_multi_raw(items, on_stream=None):
+    """items: [(x, dy, dw_buf, db_buf or None, stride, pad)] -- 2..4 weight gradients of ONE shape, accumulated into their
+    buffers by one grouped launch (srhip_conv2d_wgrad_multi) on `on_stream` (default: the current stream)."""
+    x0, dy0, dw0, _, stride, pad = items[0]
+    n, cin, h, wd = x0.shape
+    cout, _, kh, kw = dw0.shape
+    lib = _hip.lib()
+    k = len(items)
+    tab = ctypes.c_void_p * k
+    xs = tab(*[it[0].data_ptr() for it in items])
+    dys = tab(*[it[1].data_ptr() for it in items])
+    dws = tab(*[it[2].data_ptr() for it in items])
+    dbs = tab(*[(it[3].data_ptr() if it[3] is not None else None) for it in items])
+    nbytes = lib.srhip_conv2d_wgrad_workspace(n, h, wd, cin, cout, kh, kw, stride, pad)
+    if on_stream is not None:
+        ws = _side_workspace(nbytes, x0.device, on_stream)
+        st = ctypes.c_void_p(on_stream.cuda_stream)
+    else:
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, device=x0.device, dtype=torch.float32)
+        st = _stream()
+    _hip.check(lib.srhip_conv2d_wgrad_multi(k, xs, dys, dws, dbs, 1, _p(ws), ws.numel() * 4, n, h, wd, cin, cout, kh, kw,
+                                           stride, pad, cin, cout, st), 'conv2d_wgrad_multi')
+
+
+def _flush_key(key):
+    items = _state.pending.pop(key, None)
+    if not items:
+        return
+    side = _state.wgrad_stream
+    _fork_side(side, [it[6] for it in items])
+    items = [it[:6] for it in items]
+    if len(items) == 1:
+        x, dy, gw, gb, stride, pad = items[0]
+        if _state.capturing or not _FORK_C:
+            with torch.cuda.stream(side):
+                conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb))
+        else:
+            conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb), on_stream=side)
+    elif _state.capturing or not _FORK_C:
+        with torch.cuda.stream(side):
+            conv2d_wgrad_multi_raw(items)
+    else:
+        conv2d_wgrad_multi_raw(items, on_stream=side)
+    for it in items:
+        it[0].record_stream(side)
+        it[1].record_stream(side)
+
+
+def flush_pending_wgrads():
+    """Launches every weight gradient that is still waiting for a partner of its shape.  Called wherever something is about to
+    order itself behind "all weight gradients so far": the exchange, the joins of the step, the end of direct_param_grads()."""
+    if _state.pending:
+        for key in list(_state.pending):
+            _flush_key(key)
+
+
 def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscale=None):
     """(dw, db) to return to autograd for parameters (w, b).  In direct_param_grads() mode the kernel
     accumulates into w.grad / b.grad and this returns (None, None)."""
@@ -404,6 +478,17 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
         # run them on a side stream so the partially filled last wave of each data-gradient kernel and of
         # each wgrad kernel overlap.  Same-parameter accumulations stay ordered (one side stream).
         x, dy = nhwc(x), nhwc(dy)
+        if (_state.wgrad_group > 1 and xrowscale is None and xchanscale is None and (gb is not None or not want_b)
+                and _hip.lib().srhip_conv2d_wgrad_multi_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout, kh, kw, stride, pad)
+                >= _state.wgrad_group):
+            # nothing reads a weight gradient before the optimiser: wait for a partner of the same shape (the next RAB's) and
+            # launch them together -- one full wave of blocks serves both with half the split-K partials each
+            key = (tuple(x.shape), cout, stride, pad, gb is not None)
+            q = _state.pending.setdefault(key, [])
+            q.append((x, dy, gw, gb, stride, pad, _stream().value))     # + the stream that produced the operands
+            if len(q) >= _state.wgrad_group:
+                _flush_key(key)
+            return None, None
         if _state.capturing or not _FORK_C:
             main = torch.cuda.current_stream()
             side.wait_stream(main)

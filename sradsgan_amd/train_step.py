@@ -86,6 +86,8 @@ class TrainStep:
         d_default = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('SRHIP_D_PRIO') == '1' else shared[1]   # knob: D stream at high priority
         self._d_stream = (d_stream or d_default) if (overlap_wgrad and dev.type == 'cuda' and os.environ.get('SRHIP_D_STREAM', '1') == '1') else None
         self._bns = [m for m in self.D.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        # weight gradients of one shape launched together (consecutive RABs): 1 = every conv on its own (A/B knob)
+        self.wgrad_group = max(1, min(4, int(os.environ.get('SRHIP_WGRAD_GROUP', '2'))))
         self._graph = None
         self._capturing = False
         self._timeline_on = os.environ.get('SRHIP_STEP_TIMELINE') == '1'
@@ -173,6 +175,7 @@ class TrainStep:
     def _exchange_start(self, which):
         """Hands a finished gradient arena to the exchange (dp.GradSync.start): called right after the backward that
         completes it has been ENQUEUED; the collective waits on events of the streams that produce the arena."""
+        ops.flush_pending_wgrads()              # grouped weight gradients still waiting for a partner go out now
         gs = self.grad_sync
         if gs is None or not gs.active or self._capturing:
             return
@@ -246,6 +249,7 @@ class TrainStep:
             t.record_stream(dside)
         # ---- main: the one walk of D(gen) ----
         torch.autograd.backward(fake_term, inputs=list(d_params) + [gen_in])
+        ops.flush_pending_wgrads()                               # the fake term's weight gradients are all on their stream
         walked_main, walked_side = main.record_event(), side.record_event()
         g_adv = gen_in.grad.mul_(-self.weight_gan)               # d(weight_gan * loss_gan) / d gen_hr
         self._mark('D(gen) walked (main)')
@@ -449,7 +453,7 @@ class TrainStep:
         side = self._wgrad_stream if self.overlap_wgrad else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())     # arena zeroing / previous Adam before any wgrad
-        with ops.direct_param_grads(side):           # wgrad kernels accumulate straight into the gradient arenas
+        with ops.direct_param_grads(side, group=self.wgrad_group):   # wgrad kernels accumulate straight into the gradient arenas
             out = self._compute(imgs_lr, imgs_hr, alpha)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update

@@ -320,6 +320,42 @@ def test_rowtap_wgrad_against_fp64(case):
     assert _rel(dw9, ref) < 1.5e-5 and _rel(dw9, dw.double()) < 5e-6
 
 
+@pytest.mark.parametrize('case', [(8, 64, 54, 54, 256, 2), (8, 256, 54, 54, 64, 2), (6, 64, 23, 37, 128, 3), (16, 64, 27, 27, 256, 4),
+                                  (4, 128, 19, 40, 64, 2)])
+def test_grouped_rowtap_wgrad_against_fp64_and_single_launches(case):
+    """srhip_conv2d_wgrad_multi: 2..4 weight gradients of one shape share ONE row-tap launch, each with 1 / nprob of the splits
+    (fewer split-K partials, one write burst, shorter reduces).  Every problem's dw / db must match fp64 at the row-tap
+    kernel's bar and its own single launch to summation-order level, with and without bias, accumulating into a pre-filled
+    buffer (the gradient arena's mode)."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    items, refs = [], []
+    with ops.conv_math('bf16x3'):
+        for i in range(k):
+            x = torch.randn(n, cin, h, w, generator=g)
+            dy = torch.randn(n, cout, h, w, generator=g)
+            ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
+            xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+            dyg = dy.to(dev).contiguous(memory_format=torch.channels_last)
+            single_dw, single_db = ops.conv2d_wgrad_raw(xg, dyg, (cout, cin, 3, 3), 1, 1, True)
+            base = torch.full((cout, cin, 3, 3), 0.25 * (i + 1), device=dev)
+            with_bias = (i % 2 == 0)
+            bbuf = torch.full((cout,), -1.0, device=dev) if with_bias else None
+            items.append((xg, dyg, base.clone(), bbuf, 1, 1))
+            refs.append((ref, dy.double().sum((0, 2, 3)), single_dw, single_db, 0.25 * (i + 1), with_bias))
+        ops.conv2d_wgrad_multi_raw(items)
+    torch.cuda.synchronize()
+    for (xg, dyg, dw_buf, db_buf, _, _), (ref, bref, sdw, sdb, fill, with_bias) in zip(items, refs):
+        dw = dw_buf - fill
+        assert _rel(dw, ref) < 1.5e-5
+        assert _rel(dw, sdw.double()) < 5e-6
+        if with_bias:
+            assert _rel(db_buf + 1.0, bref) < 5e-6
+            assert _rel(db_buf + 1.0, sdb.double()) < 5e-6
+
+
 def test_small_channel_kernels_at_full_image_size():
     """The exact-fp32 kernels that take over at >= 65536 pixels: <= 4 destination channels (generator tail conv,
     discriminator head dgrad) and the 3 -> 64 weight gradient; ragged 259 x 257 image so edge patches, the odd last

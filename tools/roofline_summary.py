@@ -30,17 +30,21 @@ for mode in ('fp32', 'bf16x3', 'half'):
     out[mode] = {}
     for key, names in KEYS.items():
         total = 0.0
+        # a grouped weight-gradient launch is ONE main kernel + one reduce per convolution: weigh every kernel by its number of
+        # dispatches relative to the main kernel's, so the figure stays "HBM bytes per launch of the dominant kernel"
+        main_calls = max([len(pmc[k].get('FETCH_SIZE', [])) for k in pmc if any(n in k for n in names) and 'reduce' not in k] or [0])
         for k in sorted(pmc):
             if not any(n in k for n in names):
                 continue
             c = pmc[k]
+            weight = (len(c.get('FETCH_SIZE', [])) / main_calls) if (main_calls and 'reduce' in k) else 1.0
             avg = lambda name: (sum(c[name]) / len(c[name])) if c.get(name) else 0.0
             fetch, write = avg('FETCH_SIZE') * 1024 * 2, avg('WRITE_SIZE') * 1024
             calls, ns = stats.get(k, (0, 0.0))
             busy = avg('SQ_VALU_MFMA_BUSY_CYCLES') / (avg('GRBM_GUI_ACTIVE') / 8 * 1024) if avg('GRBM_GUI_ACTIVE') else 0.0
             lines.append('%-72s calls %-4d avg %8.1f us  HBM read %7.1f MB (FETCH_SIZE x2) write %7.1f MB  MFMA busy %4.1f %% of SIMD-cycles  VALU/MFMA instr %.1f'
                          % (k, calls, ns / 1e3, fetch / 1e6, write / 1e6, 100 * busy, avg('SQ_INSTS_VALU') / max(avg('SQ_INSTS_MFMA'), 1)))
-            total += fetch + write
+            total += (fetch + write) * weight
         out[mode][key] = int(total)
 open(os.path.join(root, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
 json.dump(out, open(os.path.join(root, 'roofline_traffic.json'), 'w'), indent=1)
