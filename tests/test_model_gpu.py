@@ -357,6 +357,38 @@ def test_training_step_is_deterministic():
             assert torch.equal(a, b)
 
 
+def test_grouped_weight_gradient_launches_do_not_change_the_step():
+    """TrainStep pairs the weight gradients of consecutive residual blocks into one launch (srhip_conv2d_wgrad_multi, wgrad_group =
+    2).  Group sizes 1 (every conv on its own), 2 and 4 differ only in the split-K summation order of those gradients: two
+    iterations of a 4 x 3 generator at the real x4 tile (B = 8: large enough for the row-tap kernel to be the one selected) must
+    agree to summation-order level -- scalars 1e-6, first-iteration gradients 2e-5 of each tensor's scale -- and every pending
+    gradient must have been flushed before the optimiser ran (identical parameter movement pattern: no tensor left untouched)."""
+    from sradsgan_amd.train_step import TrainStep
+    res = {}
+    for group in (1, 2, 4):
+        (hg, hd, hf), _ = build_pair(4, 3, 4, DEV)
+        step = TrainStep(hg, hd, hf)
+        step.wgrad_group = group
+        scal = []
+        for it in range(2):
+            lr_img = O.det_fill('grp.lr.%d' % it, (8, 3, 54, 54), 0.5, 0.5).to(DEV)
+            hr_img = O.det_fill('grp.hr.%d' % it, (8, 3, 216, 216), 0.5, 0.5).to(DEV)
+            alpha = O.det_fill('grp.alpha.%d' % it, (8, 1, 1, 1), 0.5, 0.5).to(DEV)
+            out = step(lr_img, hr_img, alpha)
+            scal.append(torch.stack([out[k].double() for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')]).cpu())
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in hg.named_parameters()}
+        torch.cuda.synchronize()
+        res[group] = (scal, grads)
+    for group in (2, 4):
+        for a, b in zip(res[group][0], res[1][0]):
+            assert float((a - b).abs().max()) < 1e-6, (group, a, b)
+        worst = max(float((res[group][1][k] - g1).abs().max() / g1.abs().max().clamp_min(1e-12)) for k, g1 in res[1][1].items()
+                    if float(g1.abs().max()) > 0)
+        print('wgrad_group %d vs 1: worst relative gradient difference %.2e' % (group, worst))
+        assert worst < 2e-5, (group, worst)
+
+
 @pytest.mark.parametrize('scale,batch,blocks,groups', [(4, 32, 12, 3), (2, 2, 2, 2), (3, 4, 2, 1), (8, 8, 2, 2), (9, 6, 2, 1)])
 def test_first_step_of_a_model_does_not_depend_on_allocator_history(scale, batch, blocks, groups):
     """The first step of a model packs weights lazily on whichever stream needs them first (VGG's for the real batch on the
