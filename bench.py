@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
 import argparse
 import json
 import os
+import math
 import sys
 import time
 
@@ -449,7 +450,7 @@ def run_chain(args, device):
             out = step(lr, hr, alpha)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        finite = all(float(out[k]) == float(out[k]) for k in ('loss_G', 'loss_D'))
+        finite = all(math.isfinite(float(out[k])) for k in ('loss_G', 'loss_D'))
         gf = GF_PER_IMG_ITER_BY_SCALE.get(sc)
         per['x%d' % sc] = {'img_per_s': round(B * args.steps / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 2), 'lr_side': side,
                            'step_tflops': round(B * args.steps / dt * gf / 1e3, 1) if gf else None, 'losses_finite': finite,
@@ -565,17 +566,43 @@ def cpu_baseline_subprocess(iters, timeout_s=240):
                 'sample': 'CPU leg exceeded its %d s bound on this host' % timeout_s}
 
 
-def self_launch(args):
+def visible_gpu_count():
+    """GPUs this process could use, counted WITHOUT opening the GPU driver (the launcher parent must never touch HIP before
+    it spawns its ranks, and `torch.cuda.device_count()` falls back to hipGetDeviceCount when amdsmi is absent): KFD topology
+    nodes with a non-zero simd_count are the GPU agents; a *_VISIBLE_DEVICES list narrows them like the runtime would."""
+    import glob
+    n = 0
+    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            with open(path) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2 and parts[0] == 'simd_count' and int(parts[1]) > 0:
+                        n += 1
+                        break
+        except (OSError, ValueError):
+            pass
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
+def self_launch(args, script=None, argv=None, visible=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU, the same
-    environment torch.distributed.run would give them -- BEFORE this process touches the GPU (it never does: children
-    are new processes, nothing is exec'd over an initialised runtime).  Rank 0's stdout (the JSON line) is passed through."""
+    environment torch.distributed.run would give them.  This process never touches the GPU (it does not even import torch:
+    devices are counted through sysfs, children are new processes, nothing is exec'd over an initialised runtime).  Rank 0's
+    stdout (the JSON line) is passed through.  `script` / `argv` / `visible` exist for tests/test_bench_launch_cpu.py, which
+    drives this function with stub rank scripts."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()                     # counting devices does not initialise the HIP runtime
+    have = visible_gpu_count() if visible is None else visible
     if have < args.gpus:
         print('bench.py: --gpus %d but only %d GPU(s) are visible on this node' % (args.gpus, have), file=sys.stderr)
         return 2
+    script = os.path.abspath(__file__) if script is None else script
+    argv = sys.argv[1:] if argv is None else argv
     sock = socket.socket()
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
@@ -584,7 +611,7 @@ def self_launch(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     # Watch ALL ranks (torchrun's behaviour): when one dies -- OOM, ncclCommInitRank failure, the WORLD_SIZE check -- the others
     # would sit in the store rendezvous or in an RCCL collective forever, so the first non-zero exit ends the job; an overall
@@ -723,7 +750,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = {k: float(out[k]) for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')}
-    finite = all(v == v and abs(v) != float('inf') for v in losses.values())
+    finite = all(math.isfinite(v) for v in losses.values())
 
     # The same job with the conv contraction in exact fp32 (a short extra run after the timed region, every rank takes
     # part): reported next to the headline so both arithmetic modes are in one line

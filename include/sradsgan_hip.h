@@ -59,7 +59,10 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
  *          kernel, >= 100 split-K block target of the row-tap kernel
  *   key 2  extra dynamic LDS per block (occupancy limiter), key 3 ablation bits (0x100 / 0x200: timing only, wrong results;
  *          0x400: plain instead of non-temporal epilogue stores, correct results)
- *   key 4  1: the exact-fp32 SGAM kernels in every arithmetic mode (default: split-bf16 products outside SRHIP_MATH_FP32) */
+ *   key 4  1: the exact-fp32 SGAM kernels in every arithmetic mode (default: split-bf16 products outside SRHIP_MATH_FP32)
+ *   key 5  grid of the persistent patch kernel: 0 = three blocks per CU when the conv has more tiles than that (default),
+ *          n > 0 = exactly min(n, tiles) blocks whatever the tile count (tests: several tiles per block on small images),
+ *          -1 = never (one tile per block: the round-1..3 kernel) */
 int srhip_debug_set(int key, int value);
 
 /* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *

@@ -59,6 +59,7 @@ extern int g_fast_dynlds;
 extern int g_fast_ablate;
 extern int g_conv_math;
 extern int g_sgam_cfg;
+extern int g_pers_grid;
 }
 
 extern "C" {
@@ -83,6 +84,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 4) {
     g_sgam_cfg = value;
+    return SRHIP_OK;
+  }
+  if (key == 5) {
+    g_pers_grid = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

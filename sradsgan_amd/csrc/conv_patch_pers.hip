@@ -1,0 +1,373 @@
+// Persistent form of the stride-1 3x3 patch kernel (conv_fast.hip: conv_patch_kernel) for gfx950.
+//
+// conv_patch_kernel runs one 128-pixel x BN tile per block: at the bench shape 1536 blocks on 768 slots, i.e. two
+// lock-stepped rounds, each paying its own cold prologue (descriptor / address set-up, the patch and the first weight
+// tiles fetched with nothing to hide them) and its own epilogue (every block of the chip stores its 64 KB at the same
+// time while the matrix pipes idle).  Here a block stays resident and walks tiles v = blockIdx.x, + gridDim.x, ...:
+//   * the tap stream never stops at a tile boundary: during the LAST chunk of a tile the A patch of the next tile's first
+//     chunk and its first two weight tiles are already being fetched (taps 0..2 / 7..8 of the unrolled schedule), so the
+//     next tile's first MFMA follows the epilogue directly;
+//   * the epilogue stores are buffer stores with an out-of-range offset for dead rows, so every wave issues exactly NS
+//     stores per tile: they stay in flight under the next tile's taps and the counted vmcnt waits of taps 0 and 1 simply
+//     allow NS more operations (vmcnt completes in order on gfx9-class memory pipelines);
+//   * the accumulators are staged through LDS in four 16-row passes inside the patch buffer / ring slot that the last tap
+//     has just released (the next tile's prefetch occupies the others), so the block still needs 48.5 KB: 3 blocks per CU;
+// Arithmetic, product order and chunk order are those of conv_patch_kernel: results are bit-identical to it (and so to
+// fast_conv_dma_kernel<.., MATH 1>).
+#include "conv_dev.h"
+
+namespace srhip {
+
+extern int g_fast_ablate;
+
+template <int BN, int EPI, int PROD = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_pers_kernel(
+    const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
+    const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
+    PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes) {
+  constexpr int NW = 4, BK = 16;
+  constexpr int WTM = 64, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int BPW = BN / 64;                      // B DMA pieces per wave per tap
+  constexpr int MAXP = 3;                           // A patch pieces per wave: 12 pieces = 192 rows per patch
+  constexpr int PATCH_B = 12 * 1024;
+  constexpr int BSTAGE_B = BN * 64;
+  constexpr int RING0 = 2 * PATCH_B;
+  constexpr int LDS_B = 2 * PATCH_B + 3 * BSTAGE_B;
+  constexpr int QPRW = WTN / 4;                     // float4s per staged row
+  constexpr int NRD = 16 * QPRW / 64;               // float4s per lane per 16-row pass
+  constexpr int NS = 4 * NRD;                       // epilogue stores per wave per tile (always issued)
+  constexpr int STG_B = 16 * WTN * 4;               // staging bytes per wave
+  static_assert(3 * STG_B <= PATCH_B && STG_B <= BSTAGE_B, "epilogue staging must fit the released buffers");
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+  __shared__ int pix_tab[128];                      // lane-row -> (orow << 16 | ocol)
+  __shared__ __attribute__((aligned(16))) float bias_s[512];   // the bias vector: the epilogue must not issue global loads of its own
+                                                    // (hipcc would wait vmcnt(0) for them and serialise the stores behind each other)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = nblk_m * nblk_n;
+  const int tpi = pg.tiles_h * pg.tiles_w;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  if (tid < 128) {
+    int pr_, pc_;
+    patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
+    pix_tab[tid] = (pr_ << 16) | pc_;
+  }
+  if ((EPI >= 0 ? EPI : g.flags) & SRHIP_EPI_BIAS)
+    for (int i = tid; i < g.K; i += 256) bias_s[i] = bias[i];
+  __syncthreads();
+
+  // ---- tile-invariant part of the DMA addressing ----
+  const int swz = (lane >> 4) & 3;
+  const int aq = (lane & 3) ^ swz;                  // global 16-byte quad held by this lane's slot
+  int pij[MAXP];                                    // patch coordinates (pi << 16 | pj) of the row this lane feeds, -1: past the patch
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int row = (k * NW + wave) * 16 + (lane >> 2);
+    pij[k] = -1;
+    if (row < pg.PR) {
+      const int pi = row / pg.PWP;
+      pij[k] = (pi << 16) | (row - pi * pg.PWP);
+    }
+  }
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + RING0 + wave * BPW * 1024);
+  const int CC = g.C / BK;
+  int wtap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
+
+  // ---- per-tile addressing ----
+  struct TileAt {
+    int img, oh0, ow0, n0;
+  };
+  auto decode = [&](int v) {
+    const int tile = xcd_tile(v, ntiles);
+    const int tile_n = tile % nblk_n, pid = tile / nblk_n;
+    TileAt t;
+    t.n0 = tile_n * BN;
+    t.img = pid / tpi;
+    const int prem = pid - t.img * tpi;
+    const int ty = prem / pg.tiles_w, tx = prem - ty * pg.tiles_w;
+    t.oh0 = ty * pg.PH;
+    t.ow0 = tx * pg.PW;
+    return t;
+  };
+  unsigned aoffb[MAXP], boffb[BPW];
+  auto set_a = [&](const TileAt& t) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int pi = pij[k] >> 16, pj = pij[k] & 0xffff;
+      const int sh = t.oh0 + pg.lo_h + pi, sw = t.ow0 + pg.lo_w + pj;
+      const bool ok = t.n0 >= 0 && pij[k] >= 0 && sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws;
+      aoffb[k] = ok ? (unsigned)(((t.img * g.Hs + sh) * g.Ws + sw) * g.lds + aq * 4) * 4u : F_OOB;
+    }
+  };
+  auto set_b = [&](const TileAt& t) {
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+      const int n = t.n0 + wave * 16 * BPW + 16 * j + (lane >> 2);
+      boffb[j] = (t.n0 >= 0 && n < g.K) ? (unsigned)(n * g.ldw + aq * 4) * 4u : F_OOB;
+    }
+  };
+  auto issue_a = [&](int buf, int k, unsigned coff) {   // one 1 KiB piece of a patch; coff = byte offset of the chunk's channels
+    lds_dma16_buf(aoffb[k] + coff, rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
+  };
+  auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
+    const int wk = wtap[tap] + cc * BK;
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) lds_dma16_buf(boffb[j] + (unsigned)(wk * 4), rs_b, b_dst + stage * BSTAGE_B + j * 1024);
+  };
+  auto convert_piece = [&](int buf, int k) {        // fp32 -> split bf16 in place (see conv_patch_kernel)
+    float4* slot = reinterpret_cast<float4*>(lds + buf * PATCH_B + (k * NW + wave) * 1024 + lane * 16);
+    const float4 own = *slot;
+    float4 oth;
+    oth.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.x), 0xB1, 0xF, 0xF, true));
+    oth.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.y), 0xB1, 0xF, 0xF, true));
+    oth.z = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.z), 0xB1, 0xF, 0xF, true));
+    oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
+    const bool odd = aq & 1;
+    bf16x8_t hi, lo;
+    if (PROD == 0) {
+      split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
+      *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
+    } else if (!odd) {
+      *reinterpret_cast<bf16x8_t*>(slot) = round16x8<PROD>(own, oth);
+    }
+  };
+
+  // ---- fragment addressing (tile-invariant) ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  int aoff[9][TM];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * WTM + t * 32 + l31;
+    const int pt = pix_tab[r];
+    const int orow = pt >> 16, ocol = pt & 0xffff;
+    const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int a_th = (g.dh0 + (tap / 3) * g.dhs) - pg.lo_h, a_tw = (g.dw0 + (tap % 3) * g.dws) - pg.lo_w;
+      const int pr = arow + a_th * pg.PWP + a_tw;
+      aoff[tap][t] = pr * 64 + (((2 * khalf) ^ ((pr >> 2) & 3)) << 4);
+    }
+  }
+  int boff[TN];
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int row = wn * WTN + u * 32 + l31;
+    boff[u] = RING0 + row * 64 + (((2 * khalf) ^ ((row >> 2) & 3)) << 4);
+  }
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  };
+  zero_acc();
+
+  // One tap of the endless tap stream.  PAR = patch buffer of this chunk (CC is even: chunk parity), FIRST = first chunk
+  // of a tile: NS epilogue stores (or the prologue's NS dummies) sit between the two prefetched B tiles and this tap's DMAs.
+  // Every chunk has a successor -- the next chunk of the tile, or the first chunk of the block's next tile (the caller has
+  // pointed aoffb / a_coff / b_ncc at it; after the block's last tile these are out-of-range offsets: the DMAs deliver
+  // zeros into free buffers and the block drains them before it ends) -- so there is ONE schedule and no special cases.
+  auto do_tap = [&](auto tapc, auto firstc, auto parc, int cc, unsigned a_coff, int b_ncc) {
+    constexpr int TAP = decltype(tapc)::value;
+    constexpr bool FIRST = decltype(firstc)::value != 0;
+    constexpr int pbuf = decltype(parc)::value;
+    constexpr int NEWER = BPW + ((TAP >= 1 && TAP <= MAXP) ? 1 : 0) + ((FIRST && TAP < 2) ? NS : 0);
+    wait_vmcnt<NEWER>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (TAP < MAXP) issue_a(pbuf ^ 1, TAP, a_coff);
+    if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
+    else issue_b((TAP + 2) % 3, TAP + 2 - 9, b_ncc);
+    if (TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);
+    const char* pb = lds + pbuf * PATCH_B;
+    const char* sb = lds + (TAP % 3) * BSTAGE_B;
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+    int x16 = 16;                                       // opaque to the optimiser: keeps the 18 "lo" addresses out of registers
+    asm volatile("" : "+s"(x16));
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      ah[t] = *reinterpret_cast<const bf16x8_t*>(pb + aoff[TAP][t]);
+      al[t] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(pb + (aoff[TAP][t] ^ x16)) : ah[t];
+    }
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boff[u]);
+      bl[u] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16)) : bh[u];
+    }
+#pragma unroll
+    for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {   // same product order as conv_patch_kernel
+      const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
+      acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
+    }
+  };
+  // swapb: the B tiles fetched from tap 7 on belong to the next tile (nt; n0 < 0: there is none)
+  auto do_chunk = [&](auto firstc, auto parc, int cc, unsigned a_coff, int b_ncc, bool swapb, const TileAt& nt) {
+    do_tap(IC<0>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<1>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<2>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<3>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<4>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<5>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<6>(), firstc, parc, cc, a_coff, b_ncc);
+    if (swapb) set_b(nt);
+    do_tap(IC<7>(), firstc, parc, cc, a_coff, b_ncc);
+    do_tap(IC<8>(), firstc, parc, cc, a_coff, b_ncc);
+  };
+
+  // ---- epilogue of one tile: accumulators -> wave-private LDS (16 rows at a time) -> row-contiguous buffer stores ----
+  const int flags = EPI >= 0 ? EPI : (g.flags & 0x3f);
+  auto epilogue = [&](const TileAt& t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's fragment reads of the last tap are done:
+    __builtin_amdgcn_s_barrier();                        // its patch buffer and ring slot 2 are free
+    asm volatile("" ::: "memory");
+    float* wl = reinterpret_cast<float*>(wave < 3 ? lds + PATCH_B + wave * STG_B : lds + RING0 + 2 * BSTAGE_B);   // the last chunk's buffer is 1
+    int ln = lane;                                      // opaque: the per-pass addresses are recomputed per tile, not kept in registers
+    asm volatile("" : "+v"(ln));
+    const int l31e = ln & 31, khe = ln >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int tt = p >> 1, rb = (p & 1) * 8;
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        const int idx = i * 64 + ln;
+        const int row = idx / QPRW, cq = idx - row * QPRW;
+        float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+        const int pt = pix_tab[wm * WTM + tt * 32 + (p & 1) * 16 + row];
+        const int orow = pt >> 16, ocol = pt & 0xffff;
+        const int oh = t.oh0 + orow, ow = t.ow0 + ocol;
+        const int n = t.n0 + wn * WTN + cq * 4;
+        const bool ok = orow < pg.PH && oh < g.OH && ow < g.OW && n < g.K;
+        const int dpix = ok ? (t.img * g.Hd + oh) * g.Wd + ow : 0;
+        const int ns = ok ? n : 0;
+        if (flags & SRHIP_EPI_BIAS) {
+          const float4 bb = *reinterpret_cast<const float4*>(bias_s + ns);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (flags & SRHIP_EPI_LRELU) {
+          v.x = v.x > 0.f ? v.x : v.x * g.slope;
+          v.y = v.y > 0.f ? v.y : v.y * g.slope;
+          v.z = v.z > 0.f ? v.z : v.z * g.slope;
+          v.w = v.w > 0.f ? v.w : v.w * g.slope;
+        }
+        if (flags & SRHIP_EPI_ACTMASK) {
+          const float4 a4 = *reinterpret_cast<const float4*>(actmask + (size_t)dpix * g.ldd + ns);
+          v.x = a4.x > 0.f ? v.x : v.x * g.slope;
+          v.y = a4.y > 0.f ? v.y : v.y * g.slope;
+          v.z = a4.z > 0.f ? v.z : v.z * g.slope;
+          v.w = a4.w > 0.f ? v.w : v.w * g.slope;
+        }
+        if (flags & SRHIP_EPI_RESIDUAL) {
+          const float4 r4 = *reinterpret_cast<const float4*>(residual + (size_t)dpix * g.ldr + ns);
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        const unsigned eoff = ok ? (unsigned)(dpix * g.ldd + n) * 4u : F_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
+      }
+      if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    zero_acc();
+  };
+
+  // ---- the tile walk ----
+  TileAt cur = decode(blockIdx.x), nxt = cur;
+  set_a(cur);
+  set_b(cur);
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0u);
+  issue_b(0, 0, 0);
+  issue_b(1, 1, 0);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {                    // NS dropped stores: the first tile's taps 0 and 1 count like every other tile's
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    __builtin_amdgcn_raw_buffer_store_b128(z, rs_d, F_OOB + 16u * i, 0, 0);   // distinct offsets: identical stores would be merged
+  }
+  wait_vmcnt<BPW + NS>();
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+  for (int vt = blockIdx.x; vt < ntiles; vt += (int)gridDim.x) {
+    do_chunk(IC<1>(), IC<0>(), 0, (unsigned)(BK * 4), 1, false, cur);
+    for (int cc = 1; cc + 2 < CC; cc += 2) {        // CC is even: odd chunks live in patch buffer 1, even ones in 0
+      do_chunk(IC<0>(), IC<1>(), cc, (unsigned)((cc + 1) * BK * 4), cc + 1, false, cur);
+      do_chunk(IC<0>(), IC<0>(), cc + 1, (unsigned)((cc + 2) * BK * 4), cc + 2, false, cur);
+    }
+    const int vn = vt + (int)gridDim.x;
+    if (vn < ntiles) nxt = decode(vn);
+    else nxt.n0 = -1;
+    set_a(nxt);                                     // this tile's patches are all fetched: taps 0..2 fetch the next tile's first
+    do_chunk(IC<0>(), IC<1>(), CC - 1, 0u, 0, true, nxt);
+    epilogue(cur);
+    cur = nxt;
+  }
+  wait_vmcnt<0>();                                  // the zero-fill DMAs of the tile that does not exist
+}
+
+int g_pers_grid = 0;      // srhip_debug_set(5, n)
+static int g_num_cu = 0;
+static int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cu = n;
+  }
+  return g_num_cu;
+}
+
+// Launches the persistent patch kernel when it applies; returns -1 when the caller should take conv_patch_kernel instead.
+int launch_patch_pers(const float* src, const float* wsplit, const float* bias, const float* residual, const float* actmask,
+                      float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
+                      hipStream_t st) {
+  if (g.C % 32 != 0 || ((eflags & SRHIP_EPI_BIAS) && g.K > 512)) return -1;                      // an even number of 16-channel chunks: the patch-buffer parity is compile-time
+  const long dbytes = ((long)g.N * g.Hd * g.Wd - 1) * (long)g.ldd * 4L + (long)g.K * 4L;
+  if (dbytes >= (1L << 31)) return -1;
+  const long ntiles = (long)nbm * nbn;
+  int slots = 3 * num_cu();
+  slots -= slots % 8;                               // keeps a block's XCD (blockIdx % 8) fixed over its tiles
+  if (g_pers_grid < 0 || (g_pers_grid == 0 && ntiles <= slots)) return -1;   // one tile per block: nothing to pipeline
+  const int grid = g_pers_grid > 0 ? (int)(g_pers_grid < ntiles ? g_pers_grid : ntiles) : slots;
+  const unsigned db = (unsigned)dbytes;
+#define SRHIP_PP(BN_, EPI_, PROD_)                                                                                      \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, PROD_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,     \
+                       residual, actmask, dst, g, pg, nbm, nbn, db);                                                    \
+    return check_launch("conv_patch_pers");                                                                             \
+  } while (0)
+  if (prod != 0) {
+    if (wide && prod == 1) SRHIP_PP(128, -1, 1);
+    if (wide) SRHIP_PP(128, -1, 2);
+    if (prod == 1) SRHIP_PP(64, -1, 1);
+    SRHIP_PP(64, -1, 2);
+  }
+#define SRHIP_PPE(BN_)                                                     \
+  do {                                                                     \
+    if (eflags == 0) SRHIP_PP(BN_, 0, 0);                                  \
+    if (eflags == SRHIP_EPI_BIAS) SRHIP_PP(BN_, 1, 0);                     \
+    if (eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_PP(BN_, 3, 0); \
+    if (eflags == SRHIP_EPI_ACTMASK) SRHIP_PP(BN_, 32, 0);                 \
+    if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_PP(BN_, 4, 0);                 \
+    SRHIP_PP(BN_, -1, 0);                                                  \
+  } while (0)
+  if (wide) SRHIP_PPE(128);
+  SRHIP_PPE(64);
+#undef SRHIP_PPE
+#undef SRHIP_PP
+}
+
+}  // namespace srhip

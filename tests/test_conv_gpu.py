@@ -287,6 +287,45 @@ def test_patch_conv_kernel_bit_identical_to_dma_kernel(case):
     assert _rel(out[-2][0], ref) < 1.5e-5
 
 
+@pytest.mark.parametrize('grid', [1, 3, 8])
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (3, 256, 9, 20, 256), (2, 64, 27, 27, 512),
+                                  (2, 64, 3, 70, 128), (1, 64, 108, 108, 64), (3, 64, 54, 54, 256)])
+def test_persistent_patch_kernel_bit_identical_to_dma_kernel(case, grid):
+    """conv_patch_pers_kernel (round 4: resident blocks walking several tiles, next tile prefetched under the last chunk,
+    epilogue stores left in flight under the next tile's taps) against fast_conv_dma_kernel<bf16x3>, bit for bit: one block
+    walking EVERY tile (grid 1), three blocks (tile counts that do not divide), eight; fprop with bias+LeakyReLU, fprop
+    without epilogue, dgrad with activation mask + residual, dgrad plain.  srhip_debug_set(5, grid) forces the walk at any
+    tile count; (0, -2) sends small problems to the patch family at all."""
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(sum(case) + grid)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev))
+    b = torch.randn(cout, generator=g).to(dev)
+    dy = torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        return (ops.conv2d_fwd_raw(x, wt, b, 1, 1, 0.2), ops.conv2d_fwd_raw(x, wt, None, 1, 1, None),
+                ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), 1, 1, r, x, 0.2), ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), 1, 1),
+                ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), 1, 1, None, x, 0.2))
+    with ops.conv_math('bf16x3'):
+        try:
+            lib.srhip_debug_set(0, -1)
+            ref = run()
+            lib.srhip_debug_set(0, -2)
+            lib.srhip_debug_set(5, grid)
+            for rep in range(2):                 # twice: the second launch finds the buffers of the first (stale LDS / in-flight state would show)
+                got = run()
+                for a, bb in zip(ref, got):
+                    assert torch.equal(a, bb)
+        finally:
+            lib.srhip_debug_set(0, 0)
+            lib.srhip_debug_set(5, 0)
+
+
 @pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256),
                                   (1, 64, 23, 23, 128), (3, 64, 23, 22, 128), (2, 128, 19, 40, 64), (1, 64, 2, 24, 256), (3, 128, 5, 17, 128)])
 def test_rowtap_wgrad_against_fp64(case):
