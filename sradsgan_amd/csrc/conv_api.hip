@@ -23,12 +23,12 @@ __global__ void pack_batched_kernel(const PackEntry* __restrict__ tab) {
         const int co = (int)(idx / (khkw * e.cin));
         const int rem = (int)(idx - (long)co * khkw * e.cin);
         const int tap = rem / e.cin, ci = rem - tap * e.cin;
-        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap]);
+        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap], e.cout, e.cin, khkw);
       } else {
         const int ci = (int)(idx / (khkw * e.cout));
         const int rem = (int)(idx - (long)ci * khkw * e.cout);
         const int tap = rem / e.cout, co = rem - tap * e.cout;
-        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap]);
+        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap], e.cin, e.cout, khkw);
       }
     }
   } else {
@@ -60,6 +60,7 @@ extern int g_fast_ablate;
 extern int g_conv_math;
 extern int g_sgam_cfg;
 extern int g_pers_grid;
+extern int g_pers_abl;
 }
 
 extern "C" {
@@ -90,6 +91,10 @@ int srhip_debug_set(int key, int value) {
     g_pers_grid = value;
     return SRHIP_OK;
   }
+  if (key == 6) {
+    g_pers_abl = value;
+    return SRHIP_OK;
+  }
   return SRHIP_ERR_ARG;
 }
 
@@ -103,7 +108,8 @@ int srhip_get_conv_math(void) { return g_conv_math; }
 size_t srhip_packed_elems(int cout, int cin, int kh, int kw, int mode) {
   if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (mode != 0 && mode != 1)) return 0;
   const bool fast = mode == 0 ? fast_fwd_ok(cin, cout, kh, kw) : fast_dgrad_ok(cin, cout, kh, kw);
-  if (fast) return 3 * (size_t)cout * cin * kh * kw;   // fp32 + split-bf16 + fp16 sections (fast_pack_store)
+  if (fast)   // fp32 + split-bf16 + fp16 sections + the tiled split-bf16 section (fast_pack_store)
+    return 3 * (size_t)cout * cin * kh * kw + (size_t)fast_tiled_elems(mode == 0 ? cout : cin, mode == 0 ? cin : cout, kh * kw);
   const int csrc = mode == 0 ? cin : cout, cdst = mode == 0 ? cout : cin;
   return (size_t)kh * kw * csrc * legacy_packed_ld(cdst);
 }

@@ -144,7 +144,7 @@ __device__ __forceinline__ void patch_pixel(int r, int PH, int PW, unsigned gmap
 }
 
 // conv_patch_pers.hip: persistent tile-walking form of conv_patch_kernel; -1 = not applicable (caller launches conv_patch_kernel)
-int launch_patch_pers(const float* src, const float* wsplit, const float* bias, const float* residual, const float* actmask,
+int launch_patch_pers(const float* src, const float* wt, const float* bias, const float* residual, const float* actmask,
                       float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
                       hipStream_t st);
 

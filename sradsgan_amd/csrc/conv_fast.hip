@@ -1741,12 +1741,12 @@ __global__ void fast_pack_kernel(const float* __restrict__ w, float* __restrict_
     const int co = idx / (khkw * cin);
     const int rem = idx - co * khkw * cin;
     const int tap = rem / cin, ci = rem - tap * cin;
-    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap]);
+    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap], cout, cin, khkw);
   } else {
     const int ci = idx / (khkw * cout);
     const int rem = idx - ci * khkw * cout;
     const int tap = rem / cout, co = rem - tap * cout;
-    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap]);
+    fast_pack_store(packed, total, idx, w[((size_t)co * cin + ci) * khkw + tap], cin, cout, khkw);
   }
 }
 
@@ -1941,7 +1941,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       } else if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
         const float* wsplit = w16;
         if (!(g.flags & 0x400)) {                         // persistent tile walk (srhip_debug_set(5, -1): never)
-          const int rc = launch_patch_pers(src, wsplit, bias, residual, actmask, dst, g, pg, nbm, nbn, wide, prod, eflags, st);
+          const int rc = launch_patch_pers(src, wt, bias, residual, actmask, dst, g, pg, nbm, nbn, wide, prod, eflags, st);
           if (rc >= 0) return rc;
         }
         if (prod != 0) {                                  // SRHIP_MATH_HALF: run-time epilogue flags keep the variant count down

@@ -27,14 +27,21 @@ bool fast_dgrad_ok(int cin, int cout, int kh, int kw);    // source channels = c
 bool fast_wgrad_ok(int cin, int cout, int kh, int kw);
 int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int mode, hipStream_t st);
 
-// A fast packed weight holds three sections of `total` floats each:
+// A fast packed weight holds four sections; the first three have `total` floats each:
 //   [0, total)         fp32, row = destination channel, columns (tap, source channel)        (fp32-MFMA kernels)
 //   [total, 2 total)   the same matrix pre-split for the split-bf16 kernels: every aligned group of 8 columns is
 //                      stored as 8 bf16 "hi" (round-to-nearest of v) followed by 8 bf16 "lo" (rn of v - hi), so the
 //                      two 16-byte quads a lane reads are its MFMA B operands with no conversion in the kernel;
 //                      the single-product bf16 arithmetic (SRHIP_MATH_HALF on gradient data) reads the hi quads only
 //   [2 total, 3 total) the same geometry with 8 fp16 values in the hi quad (lo quad zero): SRHIP_MATH_HALF fprop
-__device__ inline void fast_pack_store(float* packed, long total, long idx, float v) {
+//   [3 total, 3 total + fast_tiled_elems)  round 4: the pre-split matrix again, TILED for conv_patch_pers_kernel: one 64-byte
+//                      row per (16-channel chunk cc, tap, destination channel n), rows ordered [cc][tap][n] with n padded
+//                      to a multiple of 16 and the four 16-byte quads of a row already XOR-swizzled by (n >> 2) & 3 -- the
+//                      weight tile of one (chunk, tap) is then ONE contiguous run of full cache lines that an LDS-DMA copies
+//                      lane-linearly (the row-major section serves the same tile as 64-byte pieces of 2304-byte rows: half
+//                      of every 128-byte line fetched from L2 was the next chunk's, 9 taps too early to be kept)
+inline long fast_tiled_elems(int ndst, int csrc, int khkw) { return (long)khkw * csrc * (((long)ndst + 15) / 16 * 16); }
+__device__ inline void fast_pack_store(float* packed, long total, long idx, float v, int ndst, int csrc, int khkw) {
   packed[idx] = v;
   const __bf16 h = (__bf16)v;
   const __bf16 l = (__bf16)(v - (float)h);
@@ -44,6 +51,15 @@ __device__ inline void fast_pack_store(float* packed, long total, long idx, floa
   _Float16* hp = reinterpret_cast<_Float16*>(packed + 2 * total) + (idx >> 3) * 16 + (idx & 7);
   hp[0] = (_Float16)v;
   hp[8] = (_Float16)0.f;
+  const int ktot = khkw * csrc;
+  const int n = (int)(idx / ktot), kcol = (int)(idx - (long)n * ktot);
+  const int tap = kcol / csrc, c = kcol - tap * csrc;
+  const int cc = c >> 4, k16 = c & 15;
+  const long ndst16 = ((long)ndst + 15) / 16 * 16;
+  const int q = 2 * (k16 >> 3), swz = (n >> 2) & 3;
+  __bf16* tp = reinterpret_cast<__bf16*>(packed + 3 * total) + (((long)cc * khkw + tap) * ndst16 + n) * 32 + (k16 & 7);
+  tp[(q ^ swz) * 8] = h;
+  tp[((q + 1) ^ swz) * 8] = l;
 }
 int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, const float* residual,
                     const float* rowscale, const float* chanscale, float* y, int n, int h, int w, int cin, int cout, int kh, int kw,

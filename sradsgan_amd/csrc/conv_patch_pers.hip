@@ -20,11 +20,23 @@ namespace srhip {
 
 extern int g_fast_ablate;
 
-template <int BN, int EPI, int PROD = 0>
+// ablation helpers: keep a value alive / make it opaque without an instruction (vector-register constraints only exist in the device pass)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KEEP_IN(x) asm volatile("" ::"v"(x))
+#define KEEP_OUT(x) asm volatile("" : "=v"(x))
+#else
+#define KEEP_IN(x) (void)(x)
+#define KEEP_OUT(x) (void)(x)
+#endif
+
+// ABL: timing-only ablations (wrong results), srhip_debug_set(6, bits) on the <128, bias+lrelu> fprop: 1 stores dropped (out-of-range
+// offsets: issued, never written), 2 no in-place conversion, 4 no MFMAs, 8 no fragment reads, 16 no B DMA in the loop, 32 no epilogue
+template <int BN, int EPI, int PROD = 0, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_pers_kernel(
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
-    PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes) {
+    PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16) {
+  constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int NW = 4, BK = 16;
   constexpr int WTM = 64, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -76,7 +88,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   const int CC = g.C / BK;
   int wtap[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
+  for (int t = 0; t < 9; ++t) {
+    const int tapidx = (g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws);
+    wtap[t] = TILED ? tapidx * ndst16 * 64 : tapidx * g.C;   // TILED: byte offset of the tap's rows inside a chunk; else packed column
+  }
+  const int wchunk = 9 * ndst16 * 64;               // TILED: bytes of one 16-channel chunk ([tap][n] rows of 64 bytes)
   __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
@@ -111,16 +127,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
       const int n = t.n0 + wave * 16 * BPW + 16 * j + (lane >> 2);
-      boffb[j] = (t.n0 >= 0 && n < g.K) ? (unsigned)(n * g.ldw + aq * 4) * 4u : F_OOB;
+      if (TILED) boffb[j] = (t.n0 >= 0 && n < g.K) ? (unsigned)(n * 64 + (lane & 3) * 16) : F_OOB;   // rows are stored pre-swizzled
+      else boffb[j] = (t.n0 >= 0 && n < g.K) ? (unsigned)(n * g.ldw + aq * 4) * 4u : F_OOB;
     }
   };
   auto issue_a = [&](int buf, int k, unsigned coff) {   // one 1 KiB piece of a patch; coff = byte offset of the chunk's channels
     lds_dma16_buf(aoffb[k] + coff, rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
   };
   auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
-    const int wk = wtap[tap] + cc * BK;
+    const unsigned wk = TILED ? (unsigned)(wtap[tap] + cc * wchunk) : (unsigned)((wtap[tap] + cc * BK) * 4);
 #pragma unroll
-    for (int j = 0; j < BPW; ++j) lds_dma16_buf(boffb[j] + (unsigned)(wk * 4), rs_b, b_dst + stage * BSTAGE_B + j * 1024);
+    for (int j = 0; j < BPW; ++j) lds_dma16_buf(boffb[j] + wk, rs_b, b_dst + stage * BSTAGE_B + j * 1024);
   };
   auto convert_piece = [&](int buf, int k) {        // fp32 -> split bf16 in place (see conv_patch_kernel)
     float4* slot = reinterpret_cast<float4*>(lds + buf * PATCH_B + (k * NW + wave) * 1024 + lane * 16);
@@ -189,14 +206,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (TAP < MAXP) issue_a(pbuf ^ 1, TAP, a_coff);
-    if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
+    if (ABL & 16) {
+#pragma unroll
+      for (int j = 0; j < BPW; ++j) lds_dma16_buf(F_OOB, rs_b, b_dst + ((TAP + 2) % 3) * BSTAGE_B + j * 1024);
+    } else if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
     else issue_b((TAP + 2) % 3, TAP + 2 - 9, b_ncc);
-    if (TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);
+    if (!(ABL & 2) && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);
     const char* pb = lds + pbuf * PATCH_B;
     const char* sb = lds + (TAP % 3) * BSTAGE_B;
     bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
     int x16 = 16;                                       // opaque to the optimiser: keeps the 18 "lo" addresses out of registers
     asm volatile("" : "+s"(x16));
+    if (ABL & 8) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { KEEP_OUT(ah[t]); KEEP_OUT(al[t]); }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) { KEEP_OUT(bh[u]); KEEP_OUT(bl[u]); }
+    } else {
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       ah[t] = *reinterpret_cast<const bf16x8_t*>(pb + aoff[TAP][t]);
@@ -207,6 +233,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boff[u]);
       bl[u] = PROD == 0 ? *reinterpret_cast<const bf16x8_t*>(sb + (boff[u] ^ 16)) : bh[u];
     }
+    }
+    if (ABL & 4) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) { KEEP_IN(ah[t]); KEEP_IN(al[t]); }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) { KEEP_IN(bh[u]); KEEP_IN(bl[u]); }
+    } else
 #pragma unroll
     for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {   // same product order as conv_patch_kernel
       const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
@@ -233,6 +266,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's fragment reads of the last tap are done:
     __builtin_amdgcn_s_barrier();                        // its patch buffer and ring slot 2 are free
     asm volatile("" ::: "memory");
+    if (ABL & 32) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) KEEP_IN(acc[t][u]);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(z, rs_d, F_OOB + 16u * i, 0, 0);
+      }
+      zero_acc();
+      return;
+    }
     float* wl = reinterpret_cast<float*>(wave < 3 ? lds + PATCH_B + wave * STG_B : lds + RING0 + 2 * BSTAGE_B);   // the last chunk's buffer is 1
     int ln = lane;                                      // opaque: the per-pass addresses are recomputed per tile, not kept in registers
     asm volatile("" : "+v"(ln));
@@ -278,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
           const float4 r4 = *reinterpret_cast<const float4*>(residual + (size_t)dpix * g.ldr + ns);
           v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
-        const unsigned eoff = ok ? (unsigned)(dpix * g.ldd + n) * 4u : F_OOB;
+        const unsigned eoff = (ok && !(ABL & 1)) ? (unsigned)(dpix * g.ldd + n) * 4u : F_OOB + ((ABL & 1) ? 16u * (unsigned)(p * NRD + i) : 0u);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -320,6 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 }
 
 int g_pers_grid = 0;      // srhip_debug_set(5, n)
+int g_pers_abl = 0;       // srhip_debug_set(6, bits): timing-only ablations of conv_patch_pers_kernel<128, bias+lrelu>
 static int g_num_cu = 0;
 static int num_cu() {
   if (g_num_cu == 0) {
@@ -331,9 +378,20 @@ static int num_cu() {
 }
 
 // Launches the persistent patch kernel when it applies; returns -1 when the caller should take conv_patch_kernel instead.
-int launch_patch_pers(const float* src, const float* wsplit, const float* bias, const float* residual, const float* actmask,
-                      float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
+int launch_patch_pers(const float* src, const float* wt, const float* bias, const float* residual, const float* actmask,
+                      float* dst, const FastGeom& g_, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
                       hipStream_t st) {
+  FastGeom g = g_;
+  // section of the packed weight this arithmetic reads (conv_internal.h): split-bf16 -> the tiled image (its own byte count in
+  // the descriptor), one bf16 product -> the row-major split section, fp16 -> the fp16 section
+  const size_t total = (size_t)(g.w_bytes >> 2);
+  const int ndst16 = (g.K + 15) / 16 * 16;
+  const float* wsplit = wt + total * (prod == 0 ? 3 : prod == 2 ? 2 : 1);
+  if (prod == 0) {
+    const long tb = (long)9 * g.C * ndst16 * 4L;
+    if (tb >= (1L << 31)) return -1;
+    g.w_bytes = (unsigned)tb;
+  }
   if (g.C % 32 != 0 || ((eflags & SRHIP_EPI_BIAS) && g.K > 512)) return -1;                      // an even number of 16-channel chunks: the patch-buffer parity is compile-time
   const long dbytes = ((long)g.N * g.Hd * g.Wd - 1) * (long)g.ldd * 4L + (long)g.K * 4L;
   if (dbytes >= (1L << 31)) return -1;
@@ -346,7 +404,7 @@ int launch_patch_pers(const float* src, const float* wsplit, const float* bias, 
 #define SRHIP_PP(BN_, EPI_, PROD_)                                                                                      \
   do {                                                                                                                  \
     hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, PROD_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,     \
-                       residual, actmask, dst, g, pg, nbm, nbn, db);                                                    \
+                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16);                                                    \
     return check_launch("conv_patch_pers");                                                                             \
   } while (0)
   if (prod != 0) {
@@ -354,6 +412,16 @@ int launch_patch_pers(const float* src, const float* wsplit, const float* bias, 
     if (wide) SRHIP_PP(128, -1, 2);
     if (prod == 1) SRHIP_PP(64, -1, 1);
     SRHIP_PP(64, -1, 2);
+  }
+  if (g_pers_abl != 0 && wide && prod == 0 && eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) {
+#define SRHIP_PA(ABL_)                                                                                                  \
+  if (g_pers_abl == ABL_) {                                                                                             \
+    hipLaunchKernelGGL((conv_patch_pers_kernel<128, 3, 0, ABL_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,      \
+                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16);                                                    \
+    return check_launch("conv_patch_pers");                                                                             \
+  }
+    SRHIP_PA(1) SRHIP_PA(2) SRHIP_PA(4) SRHIP_PA(12) SRHIP_PA(16) SRHIP_PA(32) SRHIP_PA(30) SRHIP_PA(26) SRHIP_PA(63)
+#undef SRHIP_PA
   }
 #define SRHIP_PPE(BN_)                                                     \
   do {                                                                     \

@@ -18,7 +18,7 @@ for line in p.stderr.splitlines():
     if m:
         cur = m.group(1); rows[cur] = {}
         continue
-    m = re.search(r'remark: \S+\s+([A-Za-z][A-Za-z \[\]/]*): (\S+)', line)
+    m = re.search(r'remark:(?: \S+:\d+:\d+:)?\s+([A-Za-z][A-Za-z \[\]/]*): (\S+)', line)
     if m and cur:
         rows[cur][m.group(1).strip()] = m.group(2)
 for k, v in rows.items():
