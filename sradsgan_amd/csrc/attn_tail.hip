@@ -36,7 +36,7 @@ __global__ void clam_pool_partial_kernel(const float* __restrict__ u, float* __r
   for (int p = p0 + rl; p < p1; p += 4) {
     const float v = base[(size_t)p * TC];
     s += v;
-    if (v > mx) {
+    if (pool_takes(v, mx)) {                           // NaN propagates (common.h)
       mx = v;
       am = p;
     }
@@ -51,7 +51,7 @@ __global__ void clam_pool_partial_kernel(const float* __restrict__ u, float* __r
       s += ssum[k][c];
       const float v = smax[k][c];
       const int a = sarg[k][c];
-      if (v > mx || (v == mx && a < am)) {
+      if (pool_merge_takes(v, a, mx, am)) {
         mx = v;
         am = a;
       }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void clam_mlp_kernel(const float* __restrict__
     sum += psum[o];
     const float v = pmax[o];
     const int a = parg[o];
-    if (v > m || (v == m && a < am)) {
+    if (pool_merge_takes(v, a, m, am)) {
       m = v;
       am = a;
     }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void clam_mlp_kernel(const float* __restrict__
     for (int k = 1; k < 4; ++k) {
       const float v = qm[k][c];
       const int a = qa[k][c];
-      if (v > m || (v == m && a < am)) {
+      if (pool_merge_takes(v, a, m, am)) {
         m = v;
         am = a;
       }
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void clam_mlp_kernel(const float* __restrict__
     x0 = group16_sum(x0);
     x1 = group16_sum(x1);
     if (j < hidden && part == 0) {
-      ha[j] = fmaxf(x0, 0.f);
-      hm[j] = fmaxf(x1, 0.f);
+      ha[j] = x0 < 0.f ? 0.f : x0;                     // ReLU that lets a NaN through like ATen's (fmaxf would return 0)
+      hm[j] = x1 < 0.f ? 0.f : x1;
     }
   }
   __syncthreads();
@@ -157,15 +157,15 @@ __global__ void slam_pool_kernel(const float* __restrict__ u, const float* __res
   float sum = (y0 + y1) + (y2 + y3);
   float mx = y0;
   int am = cq * 4;
-  if (y1 > mx) { mx = y1; am = cq * 4 + 1; }
-  if (y2 > mx) { mx = y2; am = cq * 4 + 2; }
-  if (y3 > mx) { mx = y3; am = cq * 4 + 3; }
+  if (pool_takes(y1, mx)) { mx = y1; am = cq * 4 + 1; }
+  if (pool_takes(y2, mx)) { mx = y2; am = cq * 4 + 2; }
+  if (pool_takes(y3, mx)) { mx = y3; am = cq * 4 + 3; }
   sum = group16_sum(sum);
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) {
     const float ov = __shfl_xor(mx, o, 16);
     const int oa = __shfl_xor(am, o, 16);
-    if (ov > mx || (ov == mx && oa < am)) {
+    if (pool_merge_takes(ov, oa, mx, am)) {
       mx = ov;
       am = oa;
     }
@@ -441,8 +441,8 @@ __global__ void clam_mlp_bwd_kernel(const float* __restrict__ ds, const float* _
       x1 += w * sm[k];
       dh += fc2[k * hidden + c] * sdl[k];
     }
-    pa[c] = fmaxf(x0, 0.f);
-    pm[c] = fmaxf(x1, 0.f);
+    pa[c] = x0 < 0.f ? 0.f : x0;
+    pm[c] = x1 < 0.f ? 0.f : x1;
     dpa[c] = x0 > 0.f ? dh : 0.f;
     dpm[c] = x1 > 0.f ? dh : 0.f;
   }

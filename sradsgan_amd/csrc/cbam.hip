@@ -19,15 +19,6 @@
 
 namespace srhip {
 
-// max-pool comparisons propagate NaN like ATen's (adaptive_max_pool2d / max(dim)): a NaN beats every number, the first
-// NaN wins among NaNs -- a NaN activation in the discriminator must surface in the loss, not be masked by the gate
-__device__ __forceinline__ bool pool_takes(float v, float mx) { return v > mx || (v != v && mx == mx); }
-__device__ __forceinline__ bool pool_merge_takes(float om, int oi, float mx, int idx) {
-  const bool on = om != om, mn = mx != mx;
-  if (on || mn) return on && (!mn || oi < idx);
-  return om > mx || (om == mx && oi < idx);
-}
-
 // ---- along hw: one block per (image, 64 channels); thread = (channel, 1 of 4 pixel lanes) ---------------------- //
 template <bool FIXED>
 __global__ __launch_bounds__(256) void cbam_pool_hw_kernel(const float* __restrict__ x, float* __restrict__ t, int* __restrict__ arg,

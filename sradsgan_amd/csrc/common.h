@@ -45,4 +45,14 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// max-pool comparisons propagate NaN like ATen's (adaptive_max_pool2d / max(dim)): a NaN beats every number, the first
+// NaN wins among NaNs -- a NaN activation must surface in the loss, not be masked by an attention gate (cbam.hip: the
+// discriminator's pair; attn_tail.hip: the generator's 48 CLAM / SLAM pools)
+__device__ __forceinline__ bool pool_takes(float v, float mx) { return v > mx || (v != v && mx == mx); }
+__device__ __forceinline__ bool pool_merge_takes(float om, int oi, float mx, int idx) {
+  const bool on = om != om, mn = mx != mx;
+  if (on || mn) return on && (!mn || oi < idx);
+  return om > mx || (om == mx && oi < idx);
+}
+
 }  // namespace srhip

@@ -10,8 +10,9 @@
 //   * the epilogue stores are buffer stores with an out-of-range offset for dead rows, so every wave issues exactly NS
 //     stores per tile: they stay in flight under the next tile's taps and the counted vmcnt waits of taps 0 and 1 simply
 //     allow NS more operations (vmcnt completes in order on gfx9-class memory pipelines);
-//   * the accumulators are staged through LDS in four 16-row passes inside the patch buffer / ring slot that the last tap
-//     has just released (the next tile's prefetch occupies the others), so the block still needs 48.5 KB: 3 blocks per CU;
+//   * the MFMA operand roles are swapped (weights = rows, pixels = columns), so a lane holds 4 consecutive channels of one pixel
+//     per register quad and stores them itself as 16-byte pieces: no LDS transpose, no barrier and ~1/3 of the address
+//     arithmetic of the staged epilogue (kept as ablation 64 for A/B: four 16-row passes through the released buffers);
 // Arithmetic, product order and chunk order are those of conv_patch_kernel: results are bit-identical to it (and so to
 // fast_conv_dma_kernel<.., MATH 1>).
 #include "conv_dev.h"
@@ -36,7 +37,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
     PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16) {
-  constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
+  constexpr bool TILED = PROD == 0;
+  constexpr int XB = (ABL & 128) ? 2 : 1, XA = (ABL & 256) ? 2 : 1;   // ablations 128 / 256: every B / A DMA issued twice (marginal cost of the streams)
+  constexpr bool DIRECT = !(ABL & 64);              // epilogue straight from the accumulators (ABL 64: staged through LDS, round-4 first form)                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int NW = 4, BK = 16;
   constexpr int WTM = 64, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -139,21 +142,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
     for (int j = 0; j < BPW; ++j) lds_dma16_buf(boffb[j] + wk, rs_b, b_dst + stage * BSTAGE_B + j * 1024);
   };
-  auto convert_piece = [&](int buf, int k) {        // fp32 -> split bf16 in place (see conv_patch_kernel)
+  // fp32 -> split bf16 in place for one piece this wave fetched.  Lanes 2i, 2i+1 hold the two quads (8 consecutive channels)
+  // of a half row; afterwards the even quad's slot holds the 8 hi halves, the odd one's the 8 lo halves (as conv_patch_kernel
+  // leaves them).  Each lane splits only ITS four values (conv_patch_kernel: both lanes split all eight), then the pair swaps
+  // what the other needs with one DPP quad permutation per register: 20 VALU per piece instead of 52, same roundings.
+  auto convert_piece = [&](int buf, int k) {
     float4* slot = reinterpret_cast<float4*>(lds + buf * PATCH_B + (k * NW + wave) * 1024 + lane * 16);
     const float4 own = *slot;
-    float4 oth;
-    oth.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.x), 0xB1, 0xF, 0xF, true));
-    oth.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.y), 0xB1, 0xF, 0xF, true));
-    oth.z = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.z), 0xB1, 0xF, 0xF, true));
-    oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
     const bool odd = aq & 1;
-    bf16x8_t hi, lo;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     if (PROD == 0) {
-      split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
-      *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
-    } else if (!odd) {
-      *reinterpret_cast<bf16x8_t*>(slot) = round16x8<PROD>(own, oth);
+      const bf16x2_t h01 = {(__bf16)own.x, (__bf16)own.y}, h23 = {(__bf16)own.z, (__bf16)own.w};
+      const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
+      const bf16x2_t l01 = {(__bf16)(own.x - __uint_as_float(uh01 << 16)), (__bf16)(own.y - __uint_as_float(uh01 & 0xffff0000u))};
+      const bf16x2_t l23 = {(__bf16)(own.z - __uint_as_float(uh23 << 16)), (__bf16)(own.w - __uint_as_float(uh23 & 0xffff0000u))};
+      const unsigned ul01 = __builtin_bit_cast(unsigned, l01), ul23 = __builtin_bit_cast(unsigned, l23);
+      // the even lane keeps hi and needs the partner's hi; the odd lane keeps lo and needs the partner's lo
+      const unsigned s0 = odd ? uh01 : ul01, s1 = odd ? uh23 : ul23;
+      const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);
+      const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+      u32x4 o;
+      o.x = odd ? r0 : uh01;
+      o.y = odd ? r1 : uh23;
+      o.z = odd ? ul01 : r0;
+      o.w = odd ? ul23 : r1;
+      *reinterpret_cast<u32x4*>(slot) = o;
+    } else {
+      float4 oth;
+      oth.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.x), 0xB1, 0xF, 0xF, true));
+      oth.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.y), 0xB1, 0xF, 0xF, true));
+      oth.z = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.z), 0xB1, 0xF, 0xF, true));
+      oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
+      if (!odd) *reinterpret_cast<bf16x8_t*>(slot) = round16x8<PROD>(own, oth);
     }
   };
 
@@ -200,12 +220,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     constexpr int TAP = decltype(tapc)::value;
     constexpr bool FIRST = decltype(firstc)::value != 0;
     constexpr int pbuf = decltype(parc)::value;
-    constexpr int NEWER = BPW + ((TAP >= 1 && TAP <= MAXP) ? 1 : 0) + ((FIRST && TAP < 2) ? NS : 0);
+    constexpr int NEWER = XB * BPW + ((TAP >= 1 && TAP <= MAXP) ? XA : 0) + ((FIRST && TAP < 2) ? NS : 0);
     wait_vmcnt<NEWER>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (TAP < MAXP) issue_a(pbuf ^ 1, TAP, a_coff);
+    if (XA == 2 && TAP < MAXP) issue_a(pbuf ^ 1, TAP, a_coff);
+    if (XB == 2) {
+      if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
+      else issue_b((TAP + 2) % 3, TAP + 2 - 9, b_ncc);
+    }
     if (ABL & 16) {
 #pragma unroll
       for (int j = 0; j < BPW; ++j) lds_dma16_buf(F_OOB, rs_b, b_dst + ((TAP + 2) % 3) * BSTAGE_B + j * 1024);
@@ -243,7 +268,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
     for (int i = 0; i < nprod<PROD>() * TM * TN; ++i) {   // same product order as conv_patch_kernel
       const int grp = PROD == 0 ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
-      acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
+      // DIRECT: weights are the MFMA's row operand, pixels its columns: a lane ends up with 4 consecutive channels of ONE pixel
+      // per register quad and stores them itself (the same products summed over the same k order: bit-identical)
+      if (DIRECT) acc[t][u] = mma16<PROD>(grp == 1 ? bl[u] : bh[u], grp == 0 ? al[t] : ah[t], acc[t][u]);
+      else acc[t][u] = mma16<PROD>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
     }
   };
   // swapb: the B tiles fetched from tap 7 on belong to the next tile (nt; n0 < 0: there is none)
@@ -262,6 +290,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 
   // ---- epilogue of one tile: accumulators -> wave-private LDS (16 rows at a time) -> row-contiguous buffer stores ----
   const int flags = EPI >= 0 ? EPI : (g.flags & 0x3f);
+  auto epi_math = [&](float4 v, int dpix, int ns) {
+    if (flags & SRHIP_EPI_BIAS) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias_s + ns);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    if (flags & SRHIP_EPI_LRELU) {
+      v.x = v.x > 0.f ? v.x : v.x * g.slope;
+      v.y = v.y > 0.f ? v.y : v.y * g.slope;
+      v.z = v.z > 0.f ? v.z : v.z * g.slope;
+      v.w = v.w > 0.f ? v.w : v.w * g.slope;
+    }
+    if (flags & SRHIP_EPI_ACTMASK) {
+      const float4 a4 = *reinterpret_cast<const float4*>(actmask + (size_t)dpix * g.ldd + ns);
+      v.x = a4.x > 0.f ? v.x : v.x * g.slope;
+      v.y = a4.y > 0.f ? v.y : v.y * g.slope;
+      v.z = a4.z > 0.f ? v.z : v.z * g.slope;
+      v.w = a4.w > 0.f ? v.w : v.w * g.slope;
+    }
+    if (flags & SRHIP_EPI_RESIDUAL) {
+      const float4 r4 = *reinterpret_cast<const float4*>(residual + (size_t)dpix * g.ldr + ns);
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    }
+    return v;
+  };
+  auto epilogue_direct = [&](const TileAt& t) {
+    if (ABL & 32) {
+#pragma unroll
+      for (int tt = 0; tt < TM; ++tt)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) KEEP_IN(acc[tt][u]);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(z, rs_d, F_OOB + 16u * i, 0, 0);
+      }
+      zero_acc();
+      return;
+    }
+    int ln = lane;                                      // opaque: per-tile addresses are recomputed, not kept in registers
+    asm volatile("" : "+v"(ln));
+    const int l31e = ln & 31, khe = ln >> 5;
+#pragma unroll
+    for (int tt = 0; tt < TM; ++tt) {
+      const int pt = pix_tab[wm * WTM + tt * 32 + l31e];
+      const int orow = pt >> 16, ocol = pt & 0xffff;
+      const int oh = t.oh0 + orow, ow = t.ow0 + ocol;
+      const bool okp = orow < pg.PH && oh < g.OH && ow < g.OW;
+      const int dpix = okp ? (t.img * g.Hd + oh) * g.Wd + ow : 0;
+      const int nb = t.n0 + wn * WTN + 4 * khe;
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                  // registers 4q .. 4q+3: channels u*32 + 8q + 4*khalf + 0..3
+          const int n = nb + u * 32 + 8 * q;
+          const bool ok = okp && n < g.K;
+          const int ns = ok ? n : 0;
+          float4 v = make_float4(acc[tt][u][4 * q], acc[tt][u][4 * q + 1], acc[tt][u][4 * q + 2], acc[tt][u][4 * q + 3]);
+          v = epi_math(v, dpix, ns);
+          const unsigned eoff = (ok && !(ABL & 1)) ? (unsigned)(dpix * g.ldd + n) * 4u : F_OOB + ((ABL & 1) ? 16u * (unsigned)((tt * TN + u) * 4 + q) : 0u);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
+        }
+    }
+    zero_acc();
+  };
   auto epilogue = [&](const TileAt& t) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave's fragment reads of the last tap are done:
     __builtin_amdgcn_s_barrier();                        // its patch buffer and ring slot 2 are free
@@ -339,13 +431,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0u);
   issue_b(0, 0, 0);
+  if (XB == 2) issue_b(0, 0, 0);
   issue_b(1, 1, 0);
+  if (XB == 2) issue_b(1, 1, 0);
 #pragma unroll
   for (int i = 0; i < NS; ++i) {                    // NS dropped stores: the first tile's taps 0 and 1 count like every other tile's
     const u32x4 z = {0u, 0u, 0u, 0u};
     __builtin_amdgcn_raw_buffer_store_b128(z, rs_d, F_OOB + 16u * i, 0, 0);   // distinct offsets: identical stores would be merged
   }
-  wait_vmcnt<BPW + NS>();
+  wait_vmcnt<XB * BPW + NS>();
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
   for (int vt = blockIdx.x; vt < ntiles; vt += (int)gridDim.x) {
@@ -359,7 +453,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     else nxt.n0 = -1;
     set_a(nxt);                                     // this tile's patches are all fetched: taps 0..2 fetch the next tile's first
     do_chunk(IC<0>(), IC<1>(), CC - 1, 0u, 0, true, nxt);
-    epilogue(cur);
+    if (DIRECT) epilogue_direct(cur);
+    else epilogue(cur);
     cur = nxt;
   }
   wait_vmcnt<0>();                                  // the zero-fill DMAs of the tile that does not exist
@@ -420,7 +515,7 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
                        residual, actmask, dst, g, pg, nbm, nbn, db, ndst16);                                                    \
     return check_launch("conv_patch_pers");                                                                             \
   }
-    SRHIP_PA(1) SRHIP_PA(2) SRHIP_PA(4) SRHIP_PA(12) SRHIP_PA(16) SRHIP_PA(32) SRHIP_PA(30) SRHIP_PA(26) SRHIP_PA(63)
+    SRHIP_PA(1) SRHIP_PA(2) SRHIP_PA(4) SRHIP_PA(12) SRHIP_PA(16) SRHIP_PA(32) SRHIP_PA(30) SRHIP_PA(26) SRHIP_PA(63) SRHIP_PA(64) SRHIP_PA(128) SRHIP_PA(256)
 #undef SRHIP_PA
   }
 #define SRHIP_PPE(BN_)                                                     \

@@ -83,6 +83,30 @@ def test_rab(golden):
                  ['conv1.weight', 'conv2.bias', 'ca.fc1.weight', 'sa.conv1.weight', 'conv.weight'])
 
 
+def test_nan_activation_surfaces_through_the_generator_attention_pools():
+    """The CLAM / SLAM max pools of attn_tail.hip compare with NaN propagation like ATen's max (round 3 fixed only the
+    discriminator's cbam.hip pools; with `v > mx` from -inf the generator's 48 pools dropped a NaN): one NaN activation must
+    show up in the spatial max of its channel (CLAM) and in the channel max of its pixel (SLAM), whichever lane, segment or
+    shuffle step meets it, and nowhere else."""
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 2, 64, 13, 17
+    fc1, fc2 = torch.randn(4, c, 1, 1, generator=g).to(DEV), torch.randn(c, 4, 1, 1, generator=g).to(DEV)
+    w7, wc, bc = torch.randn(1, 2, 7, 7, generator=g).to(DEV), torch.randn(c, c, 1, 1, generator=g).to(DEV), torch.randn(c, generator=g).to(DEV)
+    for (b, ch, y, x) in [(0, 0, 0, 0), (1, 63, 12, 16), (0, 21, 6, 9), (1, 34, 3, 1)]:
+        u = torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        u[b, ch, y, x] = float('nan')
+        skip = torch.zeros_like(u)
+        out, (avg, mx, arg, s_, pooled, argc, m) = ops._tail_forward(u, skip, fc1, fc2, w7, wc, bc)
+        mx = mx.cpu()
+        assert torch.isnan(mx[b, ch]) and int(torch.isnan(mx).sum()) == 1, 'CLAM max dropped or smeared the NaN'
+        # SLAM pools y = s * u over channels; s of image b is NaN for every channel once the MLP has seen the NaN, so the
+        # whole image b is NaN there and the other image is clean
+        pm = pooled.view(n, h, w, 2)[..., 1].cpu()
+        assert torch.isnan(pm[b]).all() and torch.isfinite(pm[1 - b]).all()
+        assert torch.isnan(out[b]).all() and torch.isfinite(out[1 - b]).all()
+
+
 def test_resgroup(golden):
     from sradsgan_amd import model as M
     _module_case(golden, 'resgroup', M.ResGroup(M.RAB, n_blocks=2), O.ResGroup(O.RAB, n_blocks=2), X64(),
