@@ -232,8 +232,8 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         except (OSError, ValueError):
             traffic = {}
     out = []
-    kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_kernel<128,bias+lrelu>',
-          'half': 'conv_patch_kernel<128,run-time epilogue,fp16 single product>'}[math]
+    kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_pers_kernel<128,bias+lrelu> (persistent tile walk)',
+          'half': 'conv_patch_pers_kernel<128,run-time epilogue,fp16 single product>'}[math]
     kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>',
           'half': 'wgrad_rowtap_kernel<128,64,bf16 single product>'}[math]
     # The step launches the weight gradients of consecutive RABs in pairs (srhip_conv2d_wgrad_multi): the
@@ -313,6 +313,33 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
             rec['single_conv_frac'] = round(flops / group / (one * 1e-3) / 1e12 / peak, 4)
         out.append(rec)
     return out[0], out[1]
+
+
+def in_step_probe(step_fn, batch, kind, steps=4):
+    """What the step gets: `steps` more identical training steps with the library's timing probe armed on ONE conv geometry
+    (RAB conv1, 3x3 64 -> 256 @ 54x54 at this batch: kind 1 = every fprop call, 3 = every weight-gradient call), i.e. HIP events
+    around those launches on their own launch stream while the step's other streams share the chip (srhip_probe_*,
+    include/sradsgan_hip.h).  Run AFTER the timed region so that the events are not part of `value`.  Returns
+    (average ms per convolution, calls, convolutions)."""
+    import ctypes
+    import torch
+    from sradsgan_amd import _hip
+    lib = _hip.lib()
+    cap = 1024
+    _hip.check(lib.srhip_probe_config(kind, batch, LR_SIDE, LR_SIDE, 64, 256, cap), 'probe_config')
+    try:
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+        ms = (ctypes.c_float * cap)()
+        units = (ctypes.c_int * cap)()
+        n = lib.srhip_probe_read(ms, units, cap)
+    finally:
+        lib.srhip_probe_config(0, 0, 0, 0, 0, 0, 0)
+    if n <= 0:
+        return None, 0, 0
+    convs = sum(units[i] for i in range(n))
+    return sum(ms[i] for i in range(n)) / max(convs, 1), n, convs
 
 
 def usable_cores():
@@ -798,6 +825,20 @@ def main():
         if alt is not None:
             line['exact_fp32_mode'] = alt
         line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B, not args.no_sustained)
+        if not _use_graph(args) and B == PER_GPU_BATCH:
+            # the same two kernels INSIDE the step (three streams on a power-capped chip): isolated steady state above, this below
+            peak = MATH_PEAK[conv_math][0]
+            conv_flops = 2.0 * B * LR_SIDE * LR_SIDE * 256 * 64 * 9
+            for key, kind in (('roofline', 1), ('roofline_wgrad', 3)):
+                ms_conv, calls, convs = in_step_probe(lambda: step(lr, hr, alpha), B, kind)
+                if ms_conv:
+                    line[key]['in_step_avg_launch_ms'] = round(ms_conv * (convs / calls), 4)     # per CALL, like avg_launch_ms
+                    line[key]['in_step_ms_per_convolution'] = round(ms_conv, 4)
+                    line[key]['in_step_frac'] = round(conv_flops / (ms_conv * 1e-3) / 1e12 / peak, 4)
+                    line[key]['in_step_calls_timed'] = calls
+                    line[key]['in_step_note'] = ('HIP events around every %s call of this geometry on its launch stream during 4 extra training steps '
+                                                 'after the timed region (srhip_probe_*): the other two streams of the step share the chip'
+                                                 % ('fprop' if kind == 1 else 'weight-gradient'))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
     if world > 1 or force_dist:

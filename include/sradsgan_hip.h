@@ -65,6 +65,18 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
  *          -1 = never (one tile per block: the round-1..3 kernel) */
 int srhip_debug_set(int key, int value);
 
+/* ---- in-step kernel timing probe (ABI 6; bench.py: roofline.in_step_avg_launch_ms / in_step_frac) ------------------------------ *
+ * No counterpart in the reference (it has no kernels of its own): measurement infrastructure for SURVEY §8(d).
+ * srhip_probe_config(kind, n, h, w, cin, cout, max_pairs) arms the probe: every later srhip_conv2d_fwd (kind 1),
+ * srhip_conv2d_dgrad (kind 2) or srhip_conv2d_wgrad / srhip_conv2d_wgrad_multi (kind 3) call with exactly this geometry
+ * (n, h, w = batch and INPUT image of the convolution) records a HIP event before and after its launches on its own launch
+ * stream, for the first max_pairs (<= 1024) such calls; kind 0 disarms.  srhip_probe_read(ms, units, cap) waits for the recorded
+ * events and writes the elapsed milliseconds of each call (<= cap) and, when units != NULL, the number of convolutions it
+ * processed (nprob of srhip_conv2d_wgrad_multi, else 1), returning the count (-1 on error): the time the kernel took while the
+ * step's other streams shared the chip.  Not legal under stream capture; one driving thread.                                  */
+int srhip_probe_config(int kind, int n, int h, int w, int cin, int cout, int max_pairs);
+int srhip_probe_read(float* ms, int* units, int cap);
+
 /* ---- arithmetic of the conv fprop/dgrad contraction ------------------------------------------ *
  * Replaces the implicit choice torch makes for nn.Conv2d (torch.backends.cudnn.allow_tf32, which the
  * reference leaves at its default).  Inputs, outputs and accumulation are fp32 in both modes.

@@ -17,6 +17,8 @@ SIGNATURES = {
     'srhip_abi_version': (_i, []),
     'srhip_stream_fork': (_i, [_vp, _vp]),
     'srhip_debug_set': (_i, [_i, _i]),
+    'srhip_probe_config': (_i, [_i] * 7),
+    'srhip_probe_read': (_i, [_vp, _vp, _i]),
     'srhip_set_conv_math': (_i, [_i]),
     'srhip_get_conv_math': (_i, []),
     'srhip_resample_ksize': (_i, [_i, _i, _i]),

@@ -63,7 +63,66 @@ extern int g_pers_grid;
 extern int g_pers_abl;
 }
 
+namespace srhip {
+// ---- in-step timing probe (srhip_probe_*): HIP-event pairs around the conv launches of ONE shape, on their launch stream ----
+struct Probe {
+  int kind = 0, n = 0, h = 0, w = 0, cin = 0, cout = 0, cap = 0, count = 0;
+  hipEvent_t ev[2 * 1024];
+  int units[1024];
+  int created = 0;
+};
+static Probe g_probe;
+static inline bool probe_hit(int kind, int n, int h, int w, int cin, int cout) {
+  return g_probe.kind == kind && g_probe.count < g_probe.cap && g_probe.n == n && g_probe.h == h && g_probe.w == w && g_probe.cin == cin &&
+         g_probe.cout == cout;
+}
+static inline int probe_begin(void* stream) {
+  const int i = g_probe.count;
+  (void)hipEventRecord(g_probe.ev[2 * i], as_stream(stream));
+  return i;
+}
+static inline void probe_end(int i, void* stream, int units = 1) {
+  (void)hipEventRecord(g_probe.ev[2 * i + 1], as_stream(stream));
+  g_probe.units[i] = units;
+  g_probe.count = i + 1;
+}
+}  // namespace srhip
+
 extern "C" {
+
+/* In-step kernel timing (bench.py: roofline.in_step_*).  srhip_probe_config(kind, ...) arms the probe: every later
+ * srhip_conv2d_fwd (kind 1), srhip_conv2d_dgrad (2) or srhip_conv2d_wgrad / _wgrad_multi (3) call with exactly this batch,
+ * image and channel geometry records one HIP event before and one after its launches on ITS launch stream, up to `max_pairs`
+ * (<= 1024) calls; kind 0 disarms.  srhip_probe_read waits for the recorded events and returns the elapsed milliseconds of each
+ * pair (and, in `units`, how many convolutions the call processed: nprob for srhip_conv2d_wgrad_multi, else 1): what the kernel
+ * took while the step's other streams shared the chip.  Host-side bookkeeping only; not legal under stream
+ * capture; single driving thread. */
+int srhip_probe_config(int kind, int n, int h, int w, int cin, int cout, int max_pairs) {
+  SRHIP_REQUIRE(kind >= 0 && kind <= 3 && max_pairs >= 0 && max_pairs <= 1024, "probe_config: kind 0..3, max_pairs <= 1024");
+  while (g_probe.created < 2 * max_pairs) {
+    if (hipEventCreate(&g_probe.ev[g_probe.created]) != hipSuccess) {
+      set_error("probe_config: hipEventCreate failed");
+      return SRHIP_ERR_LAUNCH;
+    }
+    ++g_probe.created;
+  }
+  g_probe.kind = kind; g_probe.n = n; g_probe.h = h; g_probe.w = w; g_probe.cin = cin; g_probe.cout = cout;
+  g_probe.cap = kind ? max_pairs : 0;
+  g_probe.count = 0;
+  return SRHIP_OK;
+}
+int srhip_probe_read(float* ms, int* units, int cap) {
+  SRHIP_REQUIRE(ms || cap == 0, "probe_read: null buffer");
+  const int n = g_probe.count < cap ? g_probe.count : cap;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_probe.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms[i], g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) {
+      set_error("probe_read: event %d not readable", i);
+      return -1;
+    }
+    if (units) units[i] = g_probe.units[i];
+  }
+  return n;
+}
 
 /* tuning/experiment knobs; key 0 = fast conv tile configuration (0 = built-in heuristic) */
 int srhip_debug_set(int key, int value) {
@@ -147,9 +206,14 @@ int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, con
   SRHIP_REQUIRE(!(flags & SRHIP_EPI_RESIDUAL) || (residual && ldr >= cout), "conv2d_fwd: EPI_RESIDUAL without residual");
   SRHIP_REQUIRE(!(flags & SRHIP_EPI_ROWSCALE) || rowscale, "conv2d_fwd: EPI_ROWSCALE without rowscale");
   SRHIP_REQUIRE(!(flags & SRHIP_EPI_CHANSCALE) || chanscale, "conv2d_fwd: EPI_CHANSCALE without chanscale");
-  if (fast_fwd_ok(cin, cout, kh, kw))
-    return fast_conv2d_fwd(x, packed, bias, residual, rowscale, chanscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
-                           ldr, slope, flags, as_stream(stream));
+  if (fast_fwd_ok(cin, cout, kh, kw)) {
+    const bool pr = probe_hit(1, n, h, w, cin, cout);
+    const int pi = pr ? probe_begin(stream) : 0;
+    const int rc = fast_conv2d_fwd(x, packed, bias, residual, rowscale, chanscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
+                                   ldr, slope, flags, as_stream(stream));
+    if (pr) probe_end(pi, stream);
+    return rc;
+  }
   SRHIP_REQUIRE(!(flags & SRHIP_EPI_CHANSCALE), "conv2d_fwd: EPI_CHANSCALE needs Cin % 16 == 0");
   return legacy_conv2d_fwd(x, packed, bias, residual, rowscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
                            ldr, slope, flags, stream);
@@ -164,9 +228,14 @@ int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const fl
   SRHIP_REQUIRE(pad <= kh - 1 && pad <= kw - 1, "conv2d_dgrad: pad > kernel-1 unsupported");
   SRHIP_REQUIRE(ldy >= cout && ldx >= cin, "conv2d_dgrad: row stride smaller than channel count");
   SRHIP_REQUIRE(!residual || ldr >= cin, "conv2d_dgrad: residual row stride smaller than channel count");
-  if (fast_dgrad_ok(cin, cout, kh, kw))
-    return fast_conv2d_dgrad(dy, packed, dx, residual, actmask, slope, n, h, w, cin, cout, kh, kw, stride, pad, ldy,
-                             ldx, ldr, accumulate, as_stream(stream));
+  if (fast_dgrad_ok(cin, cout, kh, kw)) {
+    const bool pr = probe_hit(2, n, h, w, cin, cout);
+    const int pi = pr ? probe_begin(stream) : 0;
+    const int rc = fast_conv2d_dgrad(dy, packed, dx, residual, actmask, slope, n, h, w, cin, cout, kh, kw, stride, pad, ldy,
+                                     ldx, ldr, accumulate, as_stream(stream));
+    if (pr) probe_end(pi, stream);
+    return rc;
+  }
   SRHIP_REQUIRE(!residual && !actmask, "conv2d_dgrad: fused residual/activation mask needs Cout % 16 == 0");
   return legacy_conv2d_dgrad(dy, packed, dx, n, h, w, cin, cout, kh, kw, stride, pad, ldy, ldx, accumulate, stream);
 }
@@ -193,9 +262,14 @@ int srhip_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, co
   SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0,
                 "conv2d_wgrad: bad geometry");
   SRHIP_REQUIRE(ldx >= cin && ldy >= cout, "conv2d_wgrad: row stride smaller than channel count");
-  if (fast_wgrad_ok(cin, cout, kh, kw))
-    return fast_conv2d_wgrad(x, dy, dw, db, xrowscale, xchanscale, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx,
-                             ldy, as_stream(stream));
+  if (fast_wgrad_ok(cin, cout, kh, kw)) {
+    const bool pr = probe_hit(3, n, h, w, cin, cout);
+    const int pi = pr ? probe_begin(stream) : 0;
+    const int rc = fast_conv2d_wgrad(x, dy, dw, db, xrowscale, xchanscale, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad, ldx,
+                                     ldy, as_stream(stream));
+    if (pr) probe_end(pi, stream);
+    return rc;
+  }
   SRHIP_REQUIRE(!xrowscale && !xchanscale && !accumulate,
                 "conv2d_wgrad: x scaling / accumulate need Cin % 16 == 0 and Cout % 4 == 0 (srhip_conv2d_wgrad_can_accumulate)");
   const size_t need = srhip_conv2d_wgrad_workspace(n, h, w, cin, cout, kh, kw, stride, pad);
@@ -226,8 +300,12 @@ int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* cons
   SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, "conv2d_wgrad_multi: bad geometry");
   SRHIP_REQUIRE(srhip_conv2d_wgrad_multi_ok(n, h, w, cin, cout, kh, kw, stride, pad) >= nprob,
                 "conv2d_wgrad_multi: shape / size not served for %d problems (srhip_conv2d_wgrad_multi_ok)", nprob);
-  return fast_conv2d_wgrad_multi(nprob, x, dy, dw, db, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad,
-                                 ldx, ldy, as_stream(stream));
+  const bool pr = probe_hit(3, n, h, w, cin, cout);
+  const int pi = pr ? probe_begin(stream) : 0;
+  const int rc = fast_conv2d_wgrad_multi(nprob, x, dy, dw, db, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad,
+                                         ldx, ldy, as_stream(stream));
+  if (pr) probe_end(pi, stream, nprob);
+  return rc;
 }
 
 /* Weight + bias gradient of a conv whose output went through a fused LeakyReLU, from the gradient at the ACTIVATED output:

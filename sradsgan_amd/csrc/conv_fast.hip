@@ -1728,6 +1728,90 @@ __global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce_kernel(const float
   }
 }
 
+// The same reduction, four consecutive outputs per thread (16-byte loads of the partial rows) and up to four problems of one
+// shape per launch (blockIdx.y): round 4.  The summation order of every output element is EXACTLY the scalar kernel's (split lane
+// sub sums i = sub, sub + SUB, ... round-robin into four accumulators, (s0 + s1) + (s2 + s3), then the SUB lanes in groups of
+// four), so results are bit-identical to it; what changes is the access width (dword loads ran the 38 MB of a RAB conv's
+// partials at 3.2 TB/s) and one launch per grouped weight gradient instead of one per convolution.
+struct ReduceBatch {
+  const float* partial[4];
+  const float* bias_partial[4];
+  float* dw[4];
+  float* db[4];
+};
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <int SUB>
+__global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce4_kernel(ReduceBatch rb, int nsplit, int cout, int cin, int khkw,
+                                                                      int ktot, int accumulate) {
+  __shared__ float4 red[64 * SUB];
+  const int prob = blockIdx.y;
+  const float* __restrict__ partial = rb.partial[prob];
+  const float* __restrict__ bias_partial = rb.bias_partial[prob];
+  float* __restrict__ dw = rb.dw[prob];
+  float* __restrict__ db = rb.db[prob];
+  const int e = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, sub = threadIdx.x >> 6;
+  const int total = cout * ktot;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 s0 = z, s1 = z, s2 = z, s3 = z;
+  if (e < total) {
+    int i = sub;
+    for (; i + 3 * SUB < nsplit; i += 4 * SUB) {
+      s0 = add4(s0, *reinterpret_cast<const float4*>(partial + (size_t)(i + 0 * SUB) * total + e));
+      s1 = add4(s1, *reinterpret_cast<const float4*>(partial + (size_t)(i + 1 * SUB) * total + e));
+      s2 = add4(s2, *reinterpret_cast<const float4*>(partial + (size_t)(i + 2 * SUB) * total + e));
+      s3 = add4(s3, *reinterpret_cast<const float4*>(partial + (size_t)(i + 3 * SUB) * total + e));
+    }
+    for (; i < nsplit; i += SUB) s0 = add4(s0, *reinterpret_cast<const float4*>(partial + (size_t)i * total + e));
+  } else if (db != nullptr && e < total + cout) {
+    const int co = e - total;
+    for (int i = sub; i < nsplit; i += SUB) s0 = add4(s0, *reinterpret_cast<const float4*>(bias_partial + (size_t)i * cout + co));
+  }
+  red[threadIdx.x] = add4(add4(s0, s1), add4(s2, s3));
+  __syncthreads();
+  if (sub == 0) {
+    const int t = threadIdx.x;
+    float4 v = z;
+#pragma unroll
+    for (int j = 0; j < SUB; j += 4) v = add4(v, add4(add4(red[t + 64 * j], red[t + 64 * (j + 1)]), add4(red[t + 64 * (j + 2)], red[t + 64 * (j + 3)])));
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (e < total) {
+      const int co = e / ktot, kcol = e - co * ktot;              // ktot % 4 == 0: the four outputs share co and the tap
+      const int tap = kcol / cin, ci = kcol - tap * cin;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* o = dw + ((size_t)co * cin + ci + j) * khkw + tap;
+        *o = accumulate ? *o + vv[j] : vv[j];
+      }
+    } else if (db != nullptr && e < total + cout) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) db[e - total + j] = accumulate ? db[e - total + j] + vv[j] : vv[j];
+    }
+  }
+}
+// one launch for nprob problems of one shape; false: the caller takes the scalar kernel (shapes / pointers the 16-byte form cannot serve)
+static bool launch_reduce4(int nprob, const float* const* partial, const float* const* bias_partial, float* const* dw, float* const* db,
+                           int nsplit, int cout, int cin, int khkw, int ktot, int accumulate, hipStream_t st) {
+  extern int g_wgrad_cfg;
+  if (g_wgrad_cfg == 8 || nprob < 1 || nprob > 4 || ktot % 4 != 0 || cout % 4 != 0 || cin % 4 != 0) return false;
+  ReduceBatch rb;
+  bool anydb = false;
+  for (int k = 0; k < 4; ++k) {
+    const int j = k < nprob ? k : 0;
+    rb.partial[k] = partial[j];
+    rb.bias_partial[k] = bias_partial ? bias_partial[j] : nullptr;
+    rb.dw[k] = dw[j];
+    rb.db[k] = db ? db[j] : nullptr;
+    if (((uintptr_t)rb.partial[k] | (uintptr_t)rb.bias_partial[k]) & 15) return false;
+    anydb = anydb || rb.db[k] != nullptr;
+  }
+  const long total = (long)cout * ktot + (anydb ? cout : 0);
+  if (nsplit >= 64)
+    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<16>, dim3(cdiv(total, 256), nprob), dim3(1024), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate);
+  else
+    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<4>, dim3(cdiv(total, 256), nprob), dim3(256), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate);
+  return true;
+}
+
 // OIHW -> n-major packed GEMM operand.
 // mode 0 (fprop): P[co][(kh*KW+kw)*Cin + ci]  = w[co][ci][kh][kw]
 // mode 1 (dgrad): P[ci][(kh*KW+kw)*Cout + co] = w[co][ci][kh][kw]
@@ -2118,7 +2202,7 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
 struct FastWgradPlan {
   int bm, bn, bk, nsplit, chunks_per_split;
 };
-int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, +10: register-staged kernel
+int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, 8: scalar split-K reduce kernels (rounds 1-3), +10: register-staged kernel
 // row-tap kernel (wgrad_rowtap_kernel): split-bf16, 3x3 stride 1 pad 1, Cin % 64 == 0, Cout % 4 == 0 (g_wgrad_cfg 7 turns it off)
 static int rowtap_ok(int cin, int cout, int kh, int kw, int stride, int pad) {   // 0: no, 1: 128 x (kh, 64 ci), 2: 64 x (kh, 128 ci)
   if (!(g_conv_math >= 1 && g_wgrad_cfg != 7 && (g_wgrad_cfg < 10 || g_wgrad_cfg >= 100) && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout % 4 == 0))
@@ -2251,6 +2335,14 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   int rc = check_launch("fast_wgrad");
   if (rc) return rc;
   const long total = (long)cout * g.Ktot + (db ? cout : 0);
+  {
+    const float* pp[1] = {partial};
+    const float* bp[1] = {bias_partial};
+    float* dwp[1] = {dw};
+    float* dbp[1] = {db};
+    if (g_wgrad_cfg != 6 && launch_reduce4(1, pp, bp, dwp, dbp, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate, st))
+      return check_launch("fast_wgrad_reduce4");
+  }
   if (p.nsplit >= (g_wgrad_cfg == 6 ? 256 : 64))
     hipLaunchKernelGGL(fast_wgrad_reduce_kernel<16>, dim3(cdiv(total, 64)), dim3(1024), 0, st, partial, bias_partial, dw,
                        db, p.nsplit, cout, cin, kh * kw, g.Ktot, accumulate);
@@ -2333,6 +2425,8 @@ int fast_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const
     hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
   int rc = check_launch("fast_wgrad_multi");
   if (rc) return rc;
+  if (launch_reduce4(nprob, bt.partial, bt.bias_partial, dw, db, ns, cout, cin, kh * kw, g.Ktot, accumulate, st))
+    return check_launch("fast_wgrad_multi_reduce4");
   for (int k = 0; k < nprob; ++k) {
     float* dbk = db ? db[k] : nullptr;
     const long total = (long)cout * g.Ktot + (dbk ? cout : 0);

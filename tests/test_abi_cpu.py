@@ -36,10 +36,12 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_pure_host_entry_points(lib):
-    assert lib.srhip_abi_version() >= 3
-    assert lib.srhip_packed_elems(256, 64, 3, 3, 0) == 3 * 256 * 64 * 9      # fast n-major layout: fp32 | split-bf16 | fp16 sections
+    assert lib.srhip_abi_version() >= 6
+    # fast n-major layout: fp32 | split-bf16 | fp16 sections + the tiled split-bf16 section (destination channels padded to 16)
+    assert lib.srhip_packed_elems(256, 64, 3, 3, 0) == 3 * 256 * 64 * 9 + 9 * 64 * 256
     assert lib.srhip_packed_elems(64, 3, 3, 3, 0) == 27 * 64                 # generic k-major, ld = 64
-    assert lib.srhip_packed_elems(3, 64, 3, 3, 0) == 3 * 3 * 64 * 9 and lib.srhip_packed_elems(3, 64, 3, 3, 1) == 27 * 64
+    assert lib.srhip_packed_elems(3, 64, 3, 3, 0) == 3 * 3 * 64 * 9 + 9 * 64 * 16 and lib.srhip_packed_elems(3, 64, 3, 3, 1) == 27 * 64
+    assert lib.srhip_probe_config(0, 0, 0, 0, 0, 0, 0) == 0 and lib.srhip_probe_read(None, None, 0) == 0   # disarmed probe: no GPU call
     assert lib.srhip_colsum_workspace(1000, 64) >= 64 * 4
     assert lib.srhip_conv2d_wgrad_workspace(2, 54, 54, 64, 256, 3, 3, 1, 1) >= 256 * 576 * 4
 

@@ -359,6 +359,37 @@ def test_rowtap_wgrad_against_fp64(case):
     assert _rel(dw9, ref) < 1.5e-5 and _rel(dw9, dw.double()) < 5e-6
 
 
+@pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (3, 128, 19, 40, 64), (32, 64, 54, 54, 256), (4, 64, 27, 27, 64)])
+def test_vectorised_split_k_reduce_is_bit_identical_to_the_scalar_one(case):
+    """fast_wgrad_reduce4_kernel (round 4: 16-byte loads, four outputs per thread, all problems of a grouped launch behind one
+    grid) keeps the scalar kernel's summation order element by element: weight and bias gradients are bit-identical, for single
+    and for grouped weight-gradient launches (srhip_debug_set(1, 8) selects the scalar kernels)."""
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    xs = [torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    dys = [torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+
+    def run():
+        single = ops.conv2d_wgrad_raw(xs[0], dys[0], (cout, cin, 3, 3), 1, 1, True)
+        gw = [torch.zeros(cout, cin, 3, 3, device=dev) for _ in range(2)]
+        gb = [torch.zeros(cout, device=dev) for _ in range(2)]
+        if lib.srhip_conv2d_wgrad_multi_ok(n, h, w, cin, cout, 3, 3, 1, 1) >= 2:          # the grouped launch serves this size
+            ops.conv2d_wgrad_multi_raw([(xs[i], dys[i], gw[i], gb[i], 1, 1) for i in range(2)])
+        return [single[0], single[1]] + gw + gb
+    with ops.conv_math('bf16x3'):
+        try:
+            lib.srhip_debug_set(1, 8)
+            ref = run()
+        finally:
+            lib.srhip_debug_set(1, 0)
+        got = run()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('case', [(8, 64, 54, 54, 256, 2), (8, 256, 54, 54, 64, 2), (6, 64, 23, 37, 128, 3), (16, 64, 27, 27, 256, 4),
                                   (4, 128, 19, 40, 64, 2)])
 def test_grouped_rowtap_wgrad_against_fp64_and_single_launches(case):
