@@ -430,6 +430,10 @@ def conv2d_wgrad_multi_raw(items, on_stream=None):
                                            stride, pad, cin, cout, st), 'conv2d_wgrad_multi')
 
 
+_WGRAD_DEFER = os.environ.get('SRHIP_WGRAD_DEFER', '0') == '1'     # experiment: hold every groupable weight gradient until a flush point
+_WGRAD_FLUSH_GROUP = int(os.environ.get('SRHIP_WGRAD_FLUSH_GROUP', '0'))   # convolutions per launch at a flush (0: the step's group size)
+
+
 def _flush_key(key):
     items = _state.pending.pop(key, None)
     if not items:
@@ -437,18 +441,21 @@ def _flush_key(key):
     side = _state.wgrad_stream
     _fork_side(side, [it[6] for it in items])
     items = [it[:6] for it in items]
-    if len(items) == 1:
-        x, dy, gw, gb, stride, pad = items[0]
-        if _state.capturing or not _FORK_C:
+    per = max(1, _WGRAD_FLUSH_GROUP or _state.wgrad_group)
+    for i0 in range(0, len(items), per):
+        chunk = items[i0:i0 + per]
+        if len(chunk) == 1:
+            x, dy, gw, gb, stride, pad = chunk[0]
+            if _state.capturing or not _FORK_C:
+                with torch.cuda.stream(side):
+                    conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb))
+            else:
+                conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb), on_stream=side)
+        elif _state.capturing or not _FORK_C:
             with torch.cuda.stream(side):
-                conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb))
+                conv2d_wgrad_multi_raw(chunk)
         else:
-            conv2d_wgrad_raw(x, dy, tuple(gw.shape), stride, pad, gb is not None, out=(gw, gb), on_stream=side)
-    elif _state.capturing or not _FORK_C:
-        with torch.cuda.stream(side):
-            conv2d_wgrad_multi_raw(items)
-    else:
-        conv2d_wgrad_multi_raw(items, on_stream=side)
+            conv2d_wgrad_multi_raw(chunk, on_stream=side)
     for it in items:
         it[0].record_stream(side)
         it[1].record_stream(side)
@@ -486,7 +493,7 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
             key = (tuple(x.shape), cout, stride, pad, gb is not None)
             q = _state.pending.setdefault(key, [])
             q.append((x, dy, gw, gb, stride, pad, _stream().value))     # + the stream that produced the operands
-            if len(q) >= _state.wgrad_group:
+            if len(q) >= _state.wgrad_group and not _WGRAD_DEFER:
                 _flush_key(key)
             return None, None
         if _state.capturing or not _FORK_C:
