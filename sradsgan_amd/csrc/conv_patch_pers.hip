@@ -10,9 +10,13 @@
 //   * the epilogue stores are buffer stores with an out-of-range offset for dead rows, so every wave issues exactly NS
 //     stores per tile: they stay in flight under the next tile's taps and the counted vmcnt waits of taps 0 and 1 simply
 //     allow NS more operations (vmcnt completes in order on gfx9-class memory pipelines);
-//   * the MFMA operand roles are swapped (weights = rows, pixels = columns), so a lane holds 4 consecutive channels of one pixel
-//     per register quad and stores them itself as 16-byte pieces: no LDS transpose, no barrier and ~1/3 of the address
-//     arithmetic of the staged epilogue (kept as ablation 64 for A/B: four 16-row passes through the released buffers);
+//   * the accumulators are staged through LDS in four 16-row passes inside the patch buffer / ring slot that the last tap
+//     has just released (the next tile's prefetch occupies the others), so the block still needs 50.5 KB: 3 blocks per CU.
+//     (Tried and kept as ablation 64: MFMA operand roles swapped -- weights = rows, pixels = columns -- so that a lane holds 4
+//     consecutive channels of one pixel and stores them itself, no LDS transpose, a third of the address arithmetic.  Same
+//     time in split-bf16 and TWICE the HBM write traffic: a wave instruction then writes 32 B per pixel and the memory side
+//     counts 212 MB for 95.6 MB of output (profiles/r04_roofline_pmc_direct_epilogue.txt); the store-bound `half` kernel ran
+//     102 us instead of 55.)
 // Arithmetic, product order and chunk order are those of conv_patch_kernel: results are bit-identical to it (and so to
 // fast_conv_dma_kernel<.., MATH 1>).
 #include "conv_dev.h"
@@ -37,9 +41,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
     PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16) {
-  constexpr bool TILED = PROD == 0;
+  constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int XB = (ABL & 128) ? 2 : 1, XA = (ABL & 256) ? 2 : 1;   // ablations 128 / 256: every B / A DMA issued twice (marginal cost of the streams)
-  constexpr bool DIRECT = !(ABL & 64);              // epilogue straight from the accumulators (ABL 64: staged through LDS, round-4 first form)                 // B tiles from the tiled section of the packed weight (conv_internal.h)
+  constexpr bool DIRECT = (ABL & 64) != 0;          // ablation 64: epilogue straight from the accumulators with the MFMA operand roles swapped (see the header)
   constexpr int NW = 4, BK = 16;
   constexpr int WTM = 64, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;

@@ -13,7 +13,7 @@ x = torch.randn(B, 64, 54, 54, device=dev).contiguous(memory_format=torch.channe
 w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=dev) * 0.05)
 b = torch.randn(256, device=dev) * 0.01
 fl = 2.0 * B * 54 * 54 * 256 * 64 * 9
-names = {128: 'B DMA issued twice', 256: 'A DMA issued twice', 64: 'staged epilogue (LDS transpose), pixels = MFMA rows', 0: 'full kernel', 1: 'stores dropped (OOB)', 2: 'no conversion', 4: 'no MFMA', 12: 'no MFMA, no fragment reads', 16: 'no B DMA',
+names = {64: 'direct epilogue (operand roles swapped, 32-byte stores)', 128: 'B DMA issued twice', 256: 'A DMA issued twice', 0: 'full kernel', 1: 'stores dropped (OOB)', 2: 'no conversion', 4: 'no MFMA', 12: 'no MFMA, no fragment reads', 16: 'no B DMA',
          32: 'no epilogue', 30: 'skeleton: A DMA + barriers + epilogue', 26: 'MFMA + A DMA + barriers + epilogue', 63: 'A DMA + barriers only',
          -1: 'one-tile kernel (rounds 1-3)'}
 variants = [int(v) for v in os.environ.get('VARS', '0,-1,1,32,2,16,4,12,26,30,63,0').split(',')]

@@ -5,7 +5,7 @@ rocprofv3) and MFMA-busy fraction.  Writes <dir>/summary.txt and <dir>/roofline_
 import csv, glob, json, os, re, sys, collections
 
 root = sys.argv[1]
-KEYS = {'fprop': ('conv_patch_kernel', 'fast_conv_dma_kernel'), 'wgrad': ('fast_wgrad_dma_kernel', 'wgrad_rowtap_kernel', 'fast_wgrad_reduce_kernel')}
+KEYS = {'fprop': ('conv_patch_kernel', 'conv_patch_pers_kernel', 'fast_conv_dma_kernel'), 'wgrad': ('fast_wgrad_dma_kernel', 'wgrad_rowtap_kernel', 'fast_wgrad_reduce_kernel', 'fast_wgrad_reduce4_kernel')}
 out, lines = {}, []
 
 

@@ -25,7 +25,7 @@ ops_ = {
     'conv2 dgrad 64->256 actmask': lambda: ops.conv2d_dgrad_raw(x64, w2, tuple(t256.shape), 1, 1, None, t256, 0.2),
     'conv2 fprop 256->64': lambda: ops.conv2d_fwd_raw(t256, w2, None, 1, 1, None),
 }
-with ops.conv_math('bf16x3'):
+with ops.conv_math(os.environ.get('MODE', 'bf16x3')):
     for name, fn in ops_.items():
         lib.srhip_debug_set(5, -1)
         ref = fn().clone()
