@@ -199,6 +199,16 @@ size_t srhip_attn_tail_workspace(int n);
 int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, const float* w7, float* avg, float* mx,
                         int* argmax_hw, float* s, float* pooled, int* argc, float* m, void* workspace,
                         size_t workspace_bytes, int n, int h, int w, int c, int hidden, void* stream);
+
+/* Inference form of the tail (ABI 6): out = conv1x1(SLAM(CLAM(u))) + bc + skip in TWO launches (pooling partials, one fused
+ * kernel: MLP, pooled map with its 3-pixel halo, 7x7 conv, 1x1 conv on the MFMA, gate + bias + skip epilogue) and nothing saved
+ * for a backward.  wc_packed = srhip_pack_weight(mode 0) image of the 1x1 conv (its split-bf16 section is read), bc may be NULL,
+ * workspace >= srhip_attn_tail_workspace(n).  Split-bf16 arithmetic only (SRHIP_ERR_ARG otherwise); bit-identical to
+ * srhip_attn_tail_fwd + srhip_conv2d_fwd(EPI bias|residual|rowscale|chanscale) in that mode.
+ * Replaces: the eval-mode forward of model/sradsgan.py:254-274 and :303-323 (mfeNew_validate's generator pass).          */
+int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, const float* fc2, const float* w7,
+                         const float* wc_packed, const float* bc, float* out, void* workspace, size_t workspace_bytes, int n, int h,
+                         int w, int c, int hidden, void* stream);
 /* backward, spatial half: dz = gradient at z (dgrad of the 1x1 conv).  Outputs du (partial: s * dy),
  * ds [N][64] (gradient at s), dw7 [2*7*7].  The caller back-propagates ds through sigmoid + MLP
  * (tiny, [N,64]) to davg/dmax and finishes with srhip_attn_tail_bwd_channel (in place on du).      */

@@ -48,6 +48,7 @@ SIGNATURES = {
     'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_attn_tail_workspace': (_sz, [_i]),
     'srhip_attn_tail_fwd': (_i, [_vp] * 12 + [_sz] + [_i] * 5 + [_vp]),
+    'srhip_attn_tail_eval': (_i, [_vp] * 9 + [_sz] + [_i] * 5 + [_vp]),
     'srhip_attn_tail_bwd_workspace': (_sz, [_i] * 3),
     'srhip_attn_tail_bwd_spatial': (_i, [_vp] * 10 + [_i, _vp, _sz] + [_i] * 4 + [_vp]),
     'srhip_attn_tail_mlp_workspace': (_sz, [_i, _i]),

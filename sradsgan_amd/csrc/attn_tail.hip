@@ -15,9 +15,29 @@ namespace srhip {
 constexpr int TC = 64;          // channels
 constexpr int SEG = 32;         // pooling segments per image (32 x batch blocks: 8 left most CUs idle at B = 32)
 
+// value of lane (l + N) mod 16 of this lane's 16-lane row (DPP row_ror: one VALU instruction, no LDS round trip)
+template <int N>
+__device__ __forceinline__ float row_ror16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+// Sum over the 16 lanes of a row, every lane gets the total.  Round 4: rotations instead of the xor butterfly of __shfl_xor
+// (ds_bpermute: an LDS round trip per step; the fused inference tail does 160 of them per thread).  Bit-identical to the
+// butterfly: after step k all lanes that differ only in the bits already folded hold the same value (a + b == b + a), and
+// (l + o) mod 16 lies in the same class as l ^ o, so every lane adds the same two numbers in the same order as before.
 __device__ inline float group16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  v += row_ror16<8>(v);
+  v += row_ror16<4>(v);
+  v += row_ror16<2>(v);
+  v += row_ror16<1>(v);
+  return v;
+}
+// NaN-propagating maximum over the 16 lanes of a row (value only), same argument
+__device__ inline float group16_max(float v) {
+  float o;
+  o = row_ror16<8>(v); if (pool_takes(o, v)) v = o;
+  o = row_ror16<4>(v); if (pool_takes(o, v)) v = o;
+  o = row_ror16<2>(v); if (pool_takes(o, v)) v = o;
+  o = row_ror16<1>(v); if (pool_takes(o, v)) v = o;
   return v;
 }
 
@@ -33,10 +53,24 @@ __global__ void clam_pool_partial_kernel(const float* __restrict__ u, float* __r
   const float* base = u + (size_t)b * hw * TC + c;
   float s = 0.f, mx = -INFINITY;
   int am = 0x7fffffff;
-  for (int p = p0 + rl; p < p1; p += 4) {
+  int p = p0 + rl;
+  for (; p + 28 < p1; p += 32) {                     // eight loads in flight per lane (the loop was one dependent-latency load per pass:
+    float v[8];                                      // 9 us for 12 MB at B = 16); same visiting order, same sums
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = base[(size_t)(p + 4 * j) * TC];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s += v[j];
+      if (pool_takes(v[j], mx)) {                      // NaN propagates (common.h)
+        mx = v[j];
+        am = p + 4 * j;
+      }
+    }
+  }
+  for (; p < p1; p += 4) {
     const float v = base[(size_t)p * TC];
     s += v;
-    if (pool_takes(v, mx)) {                           // NaN propagates (common.h)
+    if (pool_takes(v, mx)) {
       mx = v;
       am = p;
     }
@@ -477,6 +511,267 @@ constexpr int TAIL_BLK = 48;     // blocks per image in tail_bwd_main
 
 using namespace srhip;
 
+// ================================================================================================ //
+// Inference form of the whole tail (round 4): ONE kernel after the pooling partials.
+//     s = sigmoid(MLP(avg) + MLP(max))  ->  pooled = (mean_c, max_c)(s*u)  ->  m = sigmoid(conv7x7(pooled))
+//     out = m * (Wc (s*u)) + bc + skip
+// With grad mode off nothing has to be saved, so the four launches of srhip_attn_tail_fwd's second half and the 1x1 conv collapse
+// into one: a block owns a PH x PW tile of pixels (<= 128), recomputes s for its image from the pooling partials (64 x hidden
+// multiply-adds), pools the tile plus the 3-pixel halo the 7x7 conv needs (u is read 2.5x: 12 MB at B = 16, L2 / Infinity-Cache
+// resident right behind conv2), convolves, and runs the 64 x 64 1x1 conv of its 128 pixels on the MFMA in split-bf16 with the
+// weights as the row operand (a lane ends up with 4 consecutive channels of one pixel).  Every step keeps the arithmetic and the
+// operation order of the training-mode kernels (clam_mlp_kernel, slam_pool_kernel, slam_conv7_kernel,
+// fast_conv_dma_kernel<128, 64, bias|residual|rowscale|chanscale, split-bf16>): the output is bit-identical to the training forward.
+// ================================================================================================ //
+int g_tail_dbg = 0;     // srhip_debug_set(7, bits): timing-only ablations of attn_tail_eval_kernel (1 pooling, 2 7x7 conv, 4 MFMA, 8 epilogue)
+typedef __bf16 tl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int tl_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int EV_PITCH = 272;                       // bytes per 64-channel row of the split images (256 + 16: conflict-free b128 reads)
+constexpr int EV_MAXREG = 320;                      // pixels of the pooled region (tile + halo): 20 register slots of 16 bytes per thread
+
+__global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __restrict__ u, const float* __restrict__ skip,
+                                                             const float* __restrict__ psum, const float* __restrict__ pmax,
+                                                             const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                                             const float* __restrict__ w7, const float* __restrict__ wsplit,
+                                                             const float* __restrict__ bc, float* __restrict__ out, int h, int w,
+                                                             int hidden, int PH, int PW, int tiles_h, int tiles_w, int dbg) {
+  __shared__ __attribute__((aligned(16))) char a_img[128 * EV_PITCH];      // s*u of the tile, split hi|lo per 8 channels
+  __shared__ __attribute__((aligned(16))) char w_img[TC * EV_PITCH];       // Wc, split when it was packed
+  __shared__ float2 pooled_s[EV_MAXREG];
+  __shared__ __attribute__((aligned(16))) float s_s[TC];
+  __shared__ float sa[TC], sm[TC], ha[16], hm[16], qs[4][TC], qm[4][TC], m_s[128], sw[98];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpi = tiles_h * tiles_w;
+  // XCD-aware tile order (block i runs on XCD i % 8): each XCD walks a contiguous range of tiles, so the halo pixels two
+  // neighbouring tiles both read come out of that XCD's L2
+  int vb;
+  {
+    const int nblk = (int)gridDim.x, qd = nblk >> 3, rd = nblk & 7, xc = (int)blockIdx.x & 7;
+    vb = (xc < rd ? xc * (qd + 1) : rd * (qd + 1) + (xc - rd) * qd) + ((int)blockIdx.x >> 3);
+  }
+  const int b = vb / tpi, trem = vb - b * tpi;
+  const int ty = trem / tiles_w, tx = trem - ty * tiles_w;
+  const int oh0 = ty * PH, ow0 = tx * PW;
+  const int hw = h * w;
+
+  // ---- everything that does not depend on s is fetched first: the 1x1 conv's weights (64 rows x 256 B of the packed split section
+  // -> LDS, pitch 272), the 7x7 taps, and this thread's share of u over the tile + halo (up to 32 pixel slots x 16 bytes in
+  // registers): the MLP below runs under their latency ----
+  const int RH = PH + 6, RW = PW + 6, nreg = RH * RW;
+  const int cq = tid & 15;
+  constexpr int NSLOT = EV_MAXREG / 16;              // 16 pixels per pass of the 256 threads
+  // q / RW for q < 512 by a float multiply (exact: (q + 0.5) / RW is never within 0.5 / RW of an integer): an integer division
+  // costs ~40 VALU instructions and there are two per pixel slot
+  const float inv_rw = 1.0f / (float)RW, inv_pw = 1.0f / (float)PW;
+  float4 uv[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int qq = i * 16 + (tid >> 4);
+    const int ry = (int)(((float)qq + 0.5f) * inv_rw), rx = qq - ry * RW;
+    const int y = oh0 - 3 + ry, x = ow0 - 3 + rx;
+    const bool in = qq < nreg && y >= 0 && y < h && x >= 0 && x < w;
+    uv[i] = in ? *reinterpret_cast<const float4*>(u + ((size_t)b * hw + (size_t)y * w + x) * TC + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = i * 256 + tid;                 // 16-byte piece: row = piece / 16, quad = piece % 16
+    const float4 v = *reinterpret_cast<const float4*>(wsplit + piece * 4);
+    *reinterpret_cast<float4*>(w_img + (piece >> 4) * EV_PITCH + (piece & 15) * 16) = v;
+  }
+  if (tid < 98) sw[tid] = w7[tid];
+
+  // ---- s: clam_mlp_kernel's arithmetic on this image's pooling partials; every global operand is fetched before the first
+  // dependent instruction (the partials, this thread's fc1 row quad, this channel's fc2 row) ----
+  {
+    const int c = tid & 63, q = tid >> 6;
+    float pv[SEG / 4], pm[SEG / 4];
+#pragma unroll
+    for (int i = 0; i < SEG / 4; ++i) {
+      const int o = (b * SEG + q + 4 * i) * TC + c;
+      pv[i] = psum[o];
+      pm[i] = pmax[o];
+    }
+    const int j = tid >> 4, part = tid & 15;
+    float w1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j < hidden) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w1[k] = fc1[j * TC + part * 4 + k];
+    }
+    float w2[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) w2[jj] = (q == 0 && jj < hidden) ? fc2[c * hidden + jj] : 0.f;
+    float sum = 0.f, m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SEG / 4; ++i) {
+      sum += pv[i];
+      if (pool_takes(pm[i], m)) m = pm[i];           // values only matter here: a NaN wins, else the maximum
+    }
+    qs[q][c] = sum;
+    qm[q][c] = m;
+    __syncthreads();
+    if (q == 0) {
+      sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum += qs[k][c];
+      m = qm[0][c];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float v = qm[k][c];
+        if (pool_takes(v, m)) m = v;
+      }
+      sa[c] = sum / (float)hw;
+      sm[c] = m;
+    }
+    __syncthreads();
+    {
+      float x0 = 0.f, x1 = 0.f;
+      if (j < hidden) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          x0 += w1[k] * sa[part * 4 + k];
+          x1 += w1[k] * sm[part * 4 + k];
+        }
+      }
+      x0 = group16_sum(x0);
+      x1 = group16_sum(x1);
+      if (j < hidden && part == 0) {
+        ha[j] = x0 < 0.f ? 0.f : x0;
+        hm[j] = x1 < 0.f ? 0.f : x1;
+      }
+    }
+    __syncthreads();
+    if (q == 0) {
+      float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj)
+        if (jj < hidden) {
+          l0 += w2[jj] * ha[jj];
+          l1 += w2[jj] * hm[jj];
+        }
+      const float l = l0 + l1;
+      s_s[c] = 1.f / (1.f + expf(-l));
+    }
+    __syncthreads();
+  }
+
+  // ---- pooled over the tile + halo (slam_pool_kernel's arithmetic); the tile's own pixels also leave s*u, split, in a_img ----
+  const float4 sc = *reinterpret_cast<const float4*>(s_s + cq * 4);
+  if (!(dbg & 1))
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    const int qq = i * 16 + (tid >> 4);
+    const int ry = (int)(((float)qq + 0.5f) * inv_rw), rx = qq - ry * RW;
+    const int y = oh0 - 3 + ry, x = ow0 - 3 + rx;
+    const bool in = qq < nreg && y >= 0 && y < h && x >= 0 && x < w;
+    const float y0 = uv[i].x * sc.x, y1 = uv[i].y * sc.y, y2 = uv[i].z * sc.z, y3 = uv[i].w * sc.w;
+    float sum = (y0 + y1) + (y2 + y3);
+    float mx = y0;
+    if (pool_takes(y1, mx)) mx = y1;
+    if (pool_takes(y2, mx)) mx = y2;
+    if (pool_takes(y3, mx)) mx = y3;
+    sum = group16_sum(sum);
+    mx = group16_max(mx);                              // value-only form of the arg-max merge: the larger one, a NaN on either side stays
+    if (qq < nreg) {
+      if (cq == 0) pooled_s[qq] = in ? make_float2(sum / (float)TC, mx) : make_float2(0.f, 0.f);
+      if (in && ry >= 3 && ry < 3 + PH && rx >= 3 && rx < 3 + PW) {
+        // z = s*u of 4 channels: 8-group g = cq / 2, half hh = cq & 1: hi pair at g*32 + hh*8, lo pair 16 bytes further
+        const int r = (ry - 3) * PW + (rx - 3);
+        const tl_bf16x2 h01 = {(__bf16)y0, (__bf16)y1}, h23 = {(__bf16)y2, (__bf16)y3};
+        const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
+        const tl_bf16x2 l01 = {(__bf16)(y0 - __uint_as_float(uh01 << 16)), (__bf16)(y1 - __uint_as_float(uh01 & 0xffff0000u))};
+        const tl_bf16x2 l23 = {(__bf16)(y2 - __uint_as_float(uh23 << 16)), (__bf16)(y3 - __uint_as_float(uh23 & 0xffff0000u))};
+        char* dstp = a_img + r * EV_PITCH + (cq >> 1) * 32 + (cq & 1) * 8;
+        const tl_u32x2 hv = {uh01, uh23};
+        const tl_u32x2 lv = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+        *reinterpret_cast<tl_u32x2*>(dstp) = hv;
+        *reinterpret_cast<tl_u32x2*>(dstp + 16) = lv;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- m = sigmoid(conv7x7(pooled)) for the tile's pixels (slam_conv7_kernel's order: taps outside the IMAGE are skipped) ----
+  if (tid < PH * PW && !(dbg & 2)) {
+    const int py = (int)(((float)tid + 0.5f) * inv_pw), px = tid - py * PW;
+    const int y = oh0 + py, x = ow0 + px;
+    float acc = 0.f;
+    if (y < h && x < w) {
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) {
+        const int yy = y + kh - 3;
+        if (yy < 0 || yy >= h) continue;
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+          const int xx = x + kw - 3;
+          if (xx < 0 || xx >= w) continue;
+          const float2 p = pooled_s[(py + kh) * RW + (px + kw)];
+          acc += sw[kh * 7 + kw] * p.x;
+          acc += sw[49 + kh * 7 + kw] * p.y;
+        }
+      }
+    }
+    m_s[tid] = 1.f / (1.f + expf(-acc));
+  }
+  __syncthreads();
+
+  // ---- 1x1 conv on the MFMA: wave = 32 pixels x 64 output channels, K = 64 in four chunks, products al*bh, ah*bl, ah*bh ----
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int r = wave * 32 + l31;
+  const int rpy = (int)(((float)r + 0.5f) * inv_pw), rpx = r - rpy * PW;
+  const bool rok = r < PH * PW && oh0 + rpy < h && ow0 + rpx < w;
+  const size_t pix = (size_t)b * hw + (size_t)(oh0 + rpy) * w + (ow0 + rpx);
+  float4 sk[8];                                      // the skip values of this lane's 32 outputs: in flight under the MFMAs
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    sk[i] = rok ? *reinterpret_cast<const float4*>(skip + pix * TC + (i >> 2) * 32 + 8 * (i & 3) + 4 * khalf) : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 acc2[2];
+#pragma unroll
+  for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[uu][r] = 0.f;
+  const char* prow = a_img + (wave * 32 + l31) * EV_PITCH + khalf * 32;
+  if (!(dbg & 4))
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const tl_bf16x8 ph = *reinterpret_cast<const tl_bf16x8*>(prow + cc * 64);
+    const tl_bf16x8 pl = *reinterpret_cast<const tl_bf16x8*>(prow + cc * 64 + 16);
+    tl_bf16x8 wh[2], wl[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const char* wrow = w_img + (uu * 32 + l31) * EV_PITCH + khalf * 32 + cc * 64;
+      wh[uu] = *reinterpret_cast<const tl_bf16x8*>(wrow);
+      wl[uu] = *reinterpret_cast<const tl_bf16x8*>(wrow + 16);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[uu], pl, acc2[uu], 0, 0, 0);   // al * bh
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[uu], ph, acc2[uu], 0, 0, 0);   // ah * bl
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) acc2[uu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[uu], ph, acc2[uu], 0, 0, 0);   // ah * bh
+  }
+
+  // ---- epilogue: out = m * acc + bias + skip (epi_apply_store's order: row scale, bias, residual) ----
+  if (rok && !(dbg & 8)) {
+    const float mm = m_s[r];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = uu * 32 + 8 * q + 4 * khalf;
+        float4 v = make_float4(acc2[uu][4 * q], acc2[uu][4 * q + 1], acc2[uu][4 * q + 2], acc2[uu][4 * q + 3]);
+        v.x *= mm; v.y *= mm; v.z *= mm; v.w *= mm;
+        if (bc != nullptr) {
+          const float4 bb = *reinterpret_cast<const float4*>(bc + n);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        const float4 r4 = sk[uu * 4 + q];
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        *reinterpret_cast<float4*>(out + pix * TC + n) = v;
+      }
+  }
+}
+
 extern "C" {
 
 size_t srhip_attn_tail_workspace(int n) { return (size_t)n * (SEG > TAIL_BLK ? SEG : TAIL_BLK) * TC * 3 * sizeof(float); }
@@ -498,6 +793,45 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
   hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
   hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
   return check_launch("attn_tail_fwd");
+}
+
+/* Inference form of the tail (round 4, ABI 6): out = conv1x1(SLAM(CLAM(u))) + bc + skip in two launches (pooling partials, then one
+ * fused kernel) instead of five + the 1x1 conv; nothing is saved for a backward.  `wc_packed` is the fprop packed weight of the 1x1
+ * conv (srhip_pack_weight, mode 0: the split-bf16 section is read), bc may be NULL.  Split-bf16 arithmetic only (the caller takes
+ * srhip_attn_tail_fwd + srhip_conv2d_fwd in the other modes); bit-identical to that pair in split-bf16.
+ * Replaces: the eval-mode forward of sradsgan.py:254-274 / 303-323.                                                          */
+int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, const float* fc2, const float* w7,
+                         const float* wc_packed, const float* bc, float* out, void* workspace, size_t workspace_bytes, int n, int h,
+                         int w, int c, int hidden, void* stream) {
+  SRHIP_REQUIRE(u && skip && fc1 && fc2 && w7 && wc_packed && out, "attn_tail_eval: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_eval: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_workspace(n), "attn_tail_eval: workspace too small");
+  SRHIP_REQUIRE(srhip_get_conv_math() == SRHIP_MATH_BF16X3, "attn_tail_eval: split-bf16 arithmetic only");
+  SRHIP_REQUIRE(((((uintptr_t)u) | ((uintptr_t)skip) | ((uintptr_t)out) | ((uintptr_t)wc_packed) | ((uintptr_t)bc)) & 15) == 0, "attn_tail_eval: 16-byte aligned tensors");
+  hipStream_t st = as_stream(stream);
+  const int hw = h * w;
+  float* psum = static_cast<float*>(workspace);
+  float* pmax = psum + (size_t)n * SEG * TC;
+  int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
+  // tile: PH x PW <= 128 pixels, pooled region (PH + 6) x (PW + 6) <= EV_MAXREG, fewest dead rows over the image
+  int PH = 1, PW = 1;
+  double best = -1.0;
+  for (int pw = 4; pw <= 64 && pw <= w + 3; ++pw) {
+    int ph = 128 / pw;
+    if (ph > h) ph = h;
+    if (ph < 1 || (ph + 6) * (pw + 6) > EV_MAXREG) continue;
+    const double eff = (double)h * w / ((double)cdiv(h, ph) * cdiv(w, pw) * 128.0) - 1e-4 * (double)((ph + 6) * (pw + 6)) / (ph * pw);
+    if (eff > best) {
+      best = eff;
+      PH = ph;
+      PW = pw;
+    }
+  }
+  const int tiles_h = cdiv(h, PH), tiles_w = cdiv(w, PW);
+  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, hw);
+  hipLaunchKernelGGL(attn_tail_eval_kernel, dim3(n * tiles_h * tiles_w), dim3(256), 0, st, u, skip, psum, pmax, fc1, fc2, w7,
+                     wc_packed + (size_t)TC * TC, bc, out, h, w, hidden, PH, PW, tiles_h, tiles_w, g_tail_dbg);
+  return check_launch("attn_tail_eval");
 }
 
 size_t srhip_attn_tail_bwd_workspace(int n, int h, int w) {

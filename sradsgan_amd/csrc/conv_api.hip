@@ -62,6 +62,9 @@ extern int g_sgam_cfg;
 extern int g_pers_grid;
 extern int g_pers_abl;
 }
+extern int g_tail_dbg;
+namespace srhip {
+}
 
 namespace srhip {
 // ---- in-step timing probe (srhip_probe_*): HIP-event pairs around the conv launches of ONE shape, on their launch stream ----
@@ -152,6 +155,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 6) {
     g_pers_abl = value;
+    return SRHIP_OK;
+  }
+  if (key == 7) {
+    g_tail_dbg = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -825,6 +825,27 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
     return du, dfc1, dfc2, dw7, dwc, dbc
 
 
+_TAIL_EVAL = os.environ.get('SRHIP_TAIL_EVAL', '1') == '1'      # A/B knob: 0 = the training-mode launches in inference as well
+
+
+def _tail_eval_ok(u):
+    """Inference fast path (srhip_attn_tail_eval): grad mode off, split-bf16 arithmetic, a CUDA tensor."""
+    return _TAIL_EVAL and not torch.is_grad_enabled() and u.is_cuda and get_conv_math() == 'bf16x3'
+
+
+def _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc):
+    """conv1x1(SLAM(CLAM(u))) + bc + skip with nothing saved: two launches (sradsgan.py:254-274 in eval mode)."""
+    u, skip = nhwc(u), nhwc(skip)
+    n, c, h, w = u.shape
+    lib = _hip.lib()
+    out = torch.empty_like(u, memory_format=CL)
+    ws = torch.empty(lib.srhip_attn_tail_workspace(n) // 4, device=u.device, dtype=torch.float32)
+    _hip.check(lib.srhip_attn_tail_eval(_p(u), _p(skip), _p(fc1_w.detach().contiguous()), _p(fc2_w.detach().contiguous()),
+                                        _p(w7.detach().contiguous()), _p(packed_weight(wc, 0)), _p(bc), _p(out), _p(ws), ws.numel() * 4,
+                                        n, h, w, c, fc1_w.shape[0], _stream()), 'attn_tail_eval')
+    return out
+
+
 class _AttentionTail(Function):
     @staticmethod
     def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc):
@@ -879,6 +900,11 @@ class _RabBlock(Function):
 
 
 def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
+    if _tail_eval_ok(x):                                 # inference: three conv-sized launches + the pooling partials per block
+        _require_gpu(x, 'rab_block')
+        x = nhwc(x)
+        u = conv2d_fwd_raw(conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2), w2, b2, 1, 1)
+        return _tail_forward_eval(u, x, fc1_w, fc2_w, w7, wc, bc)
     return _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc)
 
 
@@ -889,6 +915,9 @@ def attention_tail_supported(u, fc1_w, w7, wc):
 
 def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc):
     """conv1x1(SLAM(CLAM(u))) + bc + skip  for la_mode 'CA-SA', pool 'Avg|Max', addconv, C = 64."""
+    if _tail_eval_ok(u):
+        _require_gpu(u, 'attention_tail')
+        return _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc)
     return _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc)
 
 

@@ -107,6 +107,46 @@ def test_nan_activation_surfaces_through_the_generator_attention_pools():
         assert torch.isnan(out[b]).all() and torch.isfinite(out[1 - b]).all()
 
 
+@pytest.mark.parametrize('shape', [(2, 54, 54), (1, 27, 27), (3, 10, 12), (2, 13, 70), (1, 3, 5), (2, 108, 24)])
+def test_inference_tail_is_bit_identical_to_the_training_forward(shape):
+    """srhip_attn_tail_eval (round 4: pooling partials + ONE fused kernel -- MLP, pooled map with halo, 7x7 conv, 1x1 conv on the
+    MFMA, gate + bias + skip) against the training-mode launches (srhip_attn_tail_fwd + the 1x1 conv with both scales folded):
+    every step keeps their arithmetic and order, so the outputs must be equal bit for bit, on ragged images (edge tiles, halo
+    outside the image), with and without the 1x1 conv's bias, for the whole RAB as well."""
+    from sradsgan_amd import ops, model as M
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 100 + w)
+    c = 64
+    u = torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    fc1 = torch.nn.Parameter((torch.randn(4, c, 1, 1, generator=g) * 0.3).to(DEV))
+    fc2 = torch.nn.Parameter((torch.randn(c, 4, 1, 1, generator=g) * 0.3).to(DEV))
+    w7 = torch.nn.Parameter((torch.randn(1, 2, 7, 7, generator=g) * 0.2).to(DEV))
+    wc = torch.nn.Parameter((torch.randn(c, c, 1, 1, generator=g) * 0.1).to(DEV))
+    bc = torch.nn.Parameter(torch.randn(c, generator=g).to(DEV))
+    from sradsgan_amd import _hip
+    lib = _hip.lib()
+    with ops.conv_math('bf16x3'):
+        try:
+            # small problems send the training path's 1x1 conv to the exact-fp32 register kernel: pin it to the split-bf16
+            # LDS-DMA kernel the bench sizes take (srhip_debug_set(0, -1)), whose arithmetic the fused kernel reproduces
+            lib.srhip_debug_set(0, -1)
+            for bias in (bc, None):
+                ref, _ = ops._tail_forward(u, skip, fc1, fc2, w7, wc, bias)
+                with torch.no_grad():
+                    got = ops.attention_tail(u, skip, fc1, fc2, w7, wc, bias)
+                assert torch.equal(ref, got), float((ref - got).abs().max())
+            torch.manual_seed(7)
+            rab = M.RAB(64, 64).to(DEV)
+            x = torch.randn(n, c, h, w, generator=g).to(DEV)
+            y_train = rab(x).detach()
+            with torch.no_grad():
+                y_eval = rab(x)
+            assert torch.equal(y_train, y_eval)
+        finally:
+            lib.srhip_debug_set(0, 0)
+
+
 def test_resgroup(golden):
     from sradsgan_amd import model as M
     _module_case(golden, 'resgroup', M.ResGroup(M.RAB, n_blocks=2), O.ResGroup(O.RAB, n_blocks=2), X64(),
