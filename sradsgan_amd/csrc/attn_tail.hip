@@ -224,15 +224,21 @@ __global__ void slam_conv7_kernel(const float2* __restrict__ pooled, const float
   const int y = rem / w, x = rem - y * w;
   const float2* img = pooled + b * hw;
   float acc = 0.f;
+  // Branch-free taps (round 4): a tap outside the image reads a clamped address and contributes w * 0 -- the same sum as
+  // skipping it (acc starts at +0, weights are finite) -- so the 49 loads of a thread are issued together instead of one
+  // dependent L1 round trip per iteration behind a divergent branch (10.4 -> ~3 us at B = 32)
 #pragma unroll
   for (int kh = 0; kh < 7; ++kh) {
     const int yy = y + kh - 3;
-    if (yy < 0 || yy >= h) continue;
+    const bool oky = yy >= 0 && yy < h;
+    const int yc = min(max(yy, 0), h - 1);
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw) {
       const int xx = x + kw - 3;
-      if (xx < 0 || xx >= w) continue;
-      const float2 p = img[yy * w + xx];
+      const bool ok = oky && xx >= 0 && xx < w;
+      const int xc = min(max(xx, 0), w - 1);
+      float2 p = img[yc * w + xc];
+      if (!ok) p = make_float2(0.f, 0.f);
       acc += sw[kh * 7 + kw] * p.x;
       acc += sw[49 + kh * 7 + kw] * p.y;
     }
@@ -274,14 +280,17 @@ __global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const floa
   const float* img = da + b * hw;
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-  for (int kh = 0; kh < 7; ++kh) {
+  for (int kh = 0; kh < 7; ++kh) {                   // branch-free like slam_conv7_kernel: 49 independent loads per thread
     const int yy = y - kh + 3;
-    if (yy < 0 || yy >= h) continue;
+    const bool oky = yy >= 0 && yy < h;
+    const int yc = min(max(yy, 0), h - 1);
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw) {
       const int xx = x - kw + 3;
-      if (xx < 0 || xx >= w) continue;
-      const float g = img[yy * w + xx];
+      const bool ok = oky && xx >= 0 && xx < w;
+      const int xc = min(max(xx, 0), w - 1);
+      float g = img[yc * w + xc];
+      if (!ok) g = 0.f;
       a0 += sw[kh * 7 + kw] * g;
       a1 += sw[49 + kh * 7 + kw] * g;
     }
