@@ -1812,6 +1812,99 @@ static bool launch_reduce4(int nprob, const float* const* partial, const float* 
   return true;
 }
 
+// ================================================================================================ //
+// Weight + bias gradient of the attention tail's 1x1 conv (64 -> 64) with its operand scales (round 4):
+//     dWc[co][ci] = sum_p g[p][co] * (m[p] * s[b(p)][ci] * u[p][ci]),   dbc[co] = sum_p g[p][co]
+// The generic register-staged kernel took 24.5 + 7.9 us at B = 32 for 48 MB of operands (48 launches per step).  Here the fp32
+// MFMA 32x32x2 does the contraction over PIXELS directly: with K = 2 per instruction a lane holds ONE k value, so both operands
+// are read as they lie in memory -- lanes 0-31 take pixel p, lanes 32-63 pixel p + 1, 32 consecutive channels each, no transpose
+// and no LDS.  A block owns a pixel range of ONE image (s is factored out and applied once per block), a wave walks pixel pairs
+// with four accumulator tiles (co halves x ci halves); the four waves' tiles are summed through LDS in a fixed order and leave as
+// one split-K partial for fast_wgrad_reduce4_kernel.  Exact fp32 products like the kernel it replaces.
+// ================================================================================================ //
+__global__ __launch_bounds__(256) void wgrad_1x1_scaled_kernel(const float* __restrict__ u, const float* __restrict__ gy,
+                                                               const float* __restrict__ m, const float* __restrict__ sc,
+                                                               float* __restrict__ partial, float* __restrict__ bias_partial, int hw,
+                                                               int per, int sp) {
+  __shared__ float red[4][64 * 64];
+  __shared__ float bred[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.x / sp, j = blockIdx.x - b * sp;
+  const int p_begin = j * per, p_end = min(p_begin + per, hw);
+  const size_t base = (size_t)b * hw;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  float bs0 = 0.f, bs1 = 0.f;
+  constexpr int UN = 8;                               // pixel pairs per batch; the next batch's loads are issued before this one's MFMAs
+  float g0[2][UN], g1[2][UN], x0[2][UN], x1[2][UN], mv[2][UN];
+  auto fetch = [&](int set, int pp) {
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const int p = pp + 8 * i + kh;
+      const bool ok = p < p_end;
+      const size_t o = (base + (ok ? p : p_begin)) * 64 + l31;
+      g0[set][i] = ok ? gy[o] : 0.f;
+      g1[set][i] = ok ? gy[o + 32] : 0.f;
+      x0[set][i] = ok ? u[o] : 0.f;
+      x1[set][i] = ok ? u[o + 32] : 0.f;
+      mv[set][i] = ok ? m[base + p] : 0.f;
+    }
+  };
+  auto compute = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      bs0 += g0[set][i];
+      bs1 += g1[set][i];
+      const float a0 = g0[set][i] * mv[set][i], a1 = g1[set][i] * mv[set][i];
+      acc[0][0] = mfma32f(a0, x0[set][i], acc[0][0]);
+      acc[0][1] = mfma32f(a0, x1[set][i], acc[0][1]);
+      acc[1][0] = mfma32f(a1, x0[set][i], acc[1][0]);
+      acc[1][1] = mfma32f(a1, x1[set][i], acc[1][1]);
+    }
+  };
+  int pp = p_begin + 2 * wave;
+  if (pp < p_end) {
+    fetch(0, pp);
+    for (;;) {                                        // two batches per trip: the register sets are indexed at compile time
+      const int pn = pp + 8 * UN;
+      if (pn < p_end) fetch(1, pn);
+      compute(0);
+      if (pn >= p_end) break;
+      const int pn2 = pn + 8 * UN;
+      if (pn2 < p_end) fetch(0, pn2);
+      compute(1);
+      if (pn2 >= p_end) break;
+      pp = pn2;
+    }
+  }
+  // this wave's 64 x 64 tile -> LDS [co][ci]; C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + c * 32 + l31] = acc[a][c][r];
+  bred[wave][kh][l31] = bs0;
+  bred[wave][kh][32 + l31] = bs1;
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 64 * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = i * 256 + tid;                      // co = e / 64, ci = e % 64
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    out[e] = v * sc[b * 64 + (e & 63)];
+  }
+  if (bias_partial != nullptr && tid < 64)
+    bias_partial[(size_t)blockIdx.x * 64 + tid] = ((bred[0][0][tid] + bred[0][1][tid]) + (bred[1][0][tid] + bred[1][1][tid])) +
+                                                 ((bred[2][0][tid] + bred[2][1][tid]) + (bred[3][0][tid] + bred[3][1][tid]));
+}
+
 // OIHW -> n-major packed GEMM operand.
 // mode 0 (fprop): P[co][(kh*KW+kw)*Cin + ci]  = w[co][ci][kh][kw]
 // mode 1 (dgrad): P[ci][(kh*KW+kw)*Cout + co] = w[co][ci][kh][kw]
@@ -2246,12 +2339,23 @@ static FastWgradPlan plan_fast_wgrad(long P, int cout, int ktot, int rowtap = 0)
   return p;
 }
 
+// splits per image of wgrad_1x1_scaled_kernel (the attention tail's 64 -> 64 1x1 conv): ~one block per CU, >= 64 pixels per block
+static int tail1x1_splits_per_image(int n, int hw) {
+  int sp = cdiv(256, n);                               // one block per CU: the split-K reduce of a 64 x 64 tile is latency-bound on the split count
+  if (sp > cdiv(hw, 64)) sp = cdiv(hw, 64);
+  return sp < 1 ? 1 : sp;
+}
 size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
   const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
   const long P = (long)n * ho * wo;
   if (P <= 0) return 0;
   FastWgradPlan p = plan_fast_wgrad(P, cout, kh * kw * cin, rowtap_ok(cin, cout, kh, kw, stride, pad));
-  return (size_t)p.nsplit * ((size_t)cout * kh * kw * cin + cout) * sizeof(float);
+  long ns = p.nsplit;
+  if (kh == 1 && kw == 1 && cin == 64 && cout == 64 && stride == 1 && pad == 0) {
+    const long t = (long)n * tail1x1_splits_per_image(n, h * w);
+    if (t > ns) ns = t;
+  }
+  return (size_t)ns * ((size_t)cout * kh * kw * cin + cout) * sizeof(float);
 }
 
 int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrow, const float* xchan,
@@ -2281,6 +2385,28 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
   }
   float* partial = static_cast<float*>(workspace);
   float* bias_partial = partial + (size_t)p.nsplit * cout * g.Ktot;
+  // the attention tail's 1x1 conv with both operand scales: pixel-contraction kernel (wgrad_1x1_scaled_kernel); g_wgrad_cfg 8 / 6
+  // keep the generic kernel for A/B runs
+  if (xrow && xchan && kh == 1 && kw == 1 && cin == 64 && cout == 64 && stride == 1 && pad == 0 && ldx == 64 && ldy == 64 &&
+      g_wgrad_cfg != 8 && g_wgrad_cfg != 6 && n >= 1 &&
+      workspace_bytes >= (size_t)n * tail1x1_splits_per_image(n, h * w) * ((size_t)cout * g.Ktot + cout) * sizeof(float)) {
+    const int hw = h * w;
+    const int sp = tail1x1_splits_per_image(n, hw);
+    const int per = (cdiv(hw, sp) + 1) & ~1;           // even: a pixel pair never straddles two blocks
+    const int ns = n * sp;
+    float* bp = db ? partial + (size_t)ns * cout * g.Ktot : nullptr;
+    hipLaunchKernelGGL(wgrad_1x1_scaled_kernel, dim3(ns), dim3(256), 0, st, x, dy, xrow, xchan, partial, bp, hw, per, sp);
+    int rc1 = check_launch("wgrad_1x1_scaled");
+    if (rc1) return rc1;
+    const float* pp[1] = {partial};
+    const float* bpp[1] = {bp};
+    float* dwp[1] = {dw};
+    float* dbp[1] = {db};
+    if (launch_reduce4(1, pp, bpp, dwp, dbp, ns, cout, cin, 1, g.Ktot, accumulate, st)) return check_launch("fast_wgrad_reduce4");
+    hipLaunchKernelGGL(fast_wgrad_reduce_kernel<4>, dim3(cdiv((long)cout * g.Ktot + (db ? cout : 0), 64)), dim3(256), 0, st, partial, bp, dw, db, ns,
+                       cout, cin, 1, g.Ktot, accumulate);
+    return check_launch("fast_wgrad_reduce");
+  }
   const int blocks = cdiv(cout, p.bm) * cdiv(g.Ktot, p.bn) * p.nsplit;
 #define SRHIP_LW(BM_, BN_, WM_, WN_)                                                                              \
   do {                                                                                                            \
