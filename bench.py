@@ -23,7 +23,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
 import argparse
 import json
 import os
-import math
+import math as _math
 import sys
 import time
 
@@ -477,7 +477,7 @@ def run_chain(args, device):
             out = step(lr, hr, alpha)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        finite = all(math.isfinite(float(out[k])) for k in ('loss_G', 'loss_D'))
+        finite = all(_math.isfinite(float(out[k])) for k in ('loss_G', 'loss_D'))
         gf = GF_PER_IMG_ITER_BY_SCALE.get(sc)
         per['x%d' % sc] = {'img_per_s': round(B * args.steps / dt, 2), 'ms_per_step': round(dt / args.steps * 1e3, 2), 'lr_side': side,
                            'step_tflops': round(B * args.steps / dt * gf / 1e3, 1) if gf else None, 'losses_finite': finite,
@@ -777,7 +777,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = {k: float(out[k]) for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')}
-    finite = all(math.isfinite(v) for v in losses.values())
+    finite = all(_math.isfinite(v) for v in losses.values())
 
     # The same job with the conv contraction in exact fp32 (a short extra run after the timed region, every rank takes
     # part): reported next to the headline so both arithmetic modes are in one line

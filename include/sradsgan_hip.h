@@ -40,7 +40,8 @@ extern "C" {
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
 /* `to_stream` waits for everything enqueued on `from_stream` so far (event record + stream wait, events from an internal
- * ring; legal under stream capture: it forks `to_stream` into the capture).  Host-side helper, no kernel.  */
+ * ring shared by all callers: slot counter atomic, ONE device per process; legal under stream capture: it forks `to_stream` into
+ * the capture).  Host-side helper, no kernel.  */
 int srhip_stream_fork(void* from_stream, void* to_stream);
 /* ABI 2: fast packed weights carry a second, pre-split bf16 section (srhip_packed_elems doubled for them);
  * srhip_set_conv_math / srhip_get_conv_math added.

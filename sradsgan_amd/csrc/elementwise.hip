@@ -1,5 +1,7 @@
 // HBM-bound pieces of the SRADSGAN step: activation backward, pixel shuffle, column sums.
 // All are one pass over the tensor with 16-byte accesses; roofline = HBM bandwidth.
+#include <atomic>
+#include <mutex>
 #include "conv_internal.h"
 
 #include <string.h>
@@ -236,21 +238,26 @@ int srhip_abi_version(void) { return 6; }
 // timing-less events (an event can be re-recorded once the wait that used it has been ENQUEUED: hipStreamWaitEvent
 // captures the record that is current at the call).  The weight-gradient kernels are forked to their stream ~150 times per
 // training step; from Python that is torch.cuda.Event() + record + wait + a stream context per launch.
+// Contract: ONE device per process (the events are created on the device that is current at the first call) and the
+// ring is shared by every caller -- the slot counter is atomic and creation is guarded, so two driving threads (the main thread
+// and autograd's device thread both fork) cannot hand out the same slot twice.
 int srhip_stream_fork(void* from_stream, void* to_stream) {
   constexpr int RING = 64;
   static hipEvent_t ring[RING];
-  static int created = 0, next = 0;
+  static std::atomic<unsigned> next{0};
+  static std::once_flag once;
+  static bool created = false;
   if (from_stream == to_stream) return SRHIP_OK;
-  if (!created) {
+  std::call_once(once, [&]() {
+    created = true;
     for (int i = 0; i < RING; ++i)
-      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) {
-        set_error("stream_fork: hipEventCreateWithFlags failed");
-        return SRHIP_ERR_LAUNCH;
-      }
-    created = 1;
+      if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) created = false;
+  });
+  if (!created) {
+    set_error("stream_fork: hipEventCreateWithFlags failed");
+    return SRHIP_ERR_LAUNCH;
   }
-  hipEvent_t ev = ring[next];
-  next = (next + 1) % RING;
+  hipEvent_t ev = ring[next.fetch_add(1u, std::memory_order_relaxed) % RING];
   if (hipEventRecord(ev, as_stream(from_stream)) != hipSuccess || hipStreamWaitEvent(as_stream(to_stream), ev, 0) != hipSuccess) {
     set_error("stream_fork: %s", hipGetErrorString(hipGetLastError()));
     return SRHIP_ERR_LAUNCH;

@@ -157,7 +157,7 @@ class GradSync:
         if lib.srhip_dp_world() != world:
             raise RuntimeError('GradSync: RCCL communicator has %d ranks, torch.distributed %d' % (lib.srhip_dp_world(), world))
         # HIGH priority: the exchange is enqueued tens of milliseconds ahead of its inputs, i.e. its stream sits on an
-        # event wait for most of the step.  Measured on MI355X / ROCm 7.2 (single rank, tools/gpu_r2_dist.sh): parked on
+        # event wait for most of the step.  Measured on MI355X / ROCm 7.0 (single rank, profiles/r02_bench_n1_rccl_single_rank.json): parked on
         # a normal-priority queue that wait slows the compute streams' kernels by 12 % (75.1 vs 66.6 ms per step, with or
         # without an RCCL call behind it); on a high-priority queue the step costs 66.9 ms (+0.4 %).
         self._comm_stream = torch.cuda.Stream(priority=0 if os.environ.get('SRHIP_DP_PRIO') == '0' else -1)

@@ -221,7 +221,7 @@ def _pack_fence(ent):
     for the penalty's first-order backward) and read by every stream afterwards.  Nothing else orders those reads behind
     the pack kernel: in the first step of a model the main stream could run D(gen)'s data gradients on images the D stream
     had not packed yet -- zeros on fresh memory (a silently wrong first step), NaNs on recycled memory
-    (tools/check_nan.py).  The entry carries the pack's event; a stream waits for it once."""
+    (tests/test_model_gpu.py::test_first_step_of_a_model_does_not_depend_on_allocator_history).  The entry carries the pack's event; a stream waits for it once."""
     ev = ent[5]
     if ev is None or _NO_PACK_FENCE:
         return

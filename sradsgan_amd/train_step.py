@@ -58,6 +58,14 @@ def _side_streams(dev):
     return _SIDE_STREAMS[key]
 
 
+def _join_side(stream, side):
+    """`stream` waits for the weight-gradient stream -- after every grouped weight gradient that is still waiting for a partner
+    has been launched on it: a join that did not flush first would order itself behind "all weight gradients so far" and miss the
+    held ones."""
+    ops.flush_pending_wgrads()
+    stream.wait_stream(side)
+
+
 class TrainStep:
     _timeline_on = False        # SRHIP_STEP_TIMELINE=1 (set per instance in __init__)
     max_run_ahead = 0
@@ -166,7 +174,7 @@ class TrainStep:
         backward by their sequence numbers -- and those come from two per-thread counters (forward nodes are numbered by
         the calling thread, the nodes autograd.grad(create_graph=True) creates by the engine's device thread), so which of
         the four contributions to a discriminator weight is added first depended on how much autograd work the process
-        had done before (an ulp in D's gradients; tools/check_graph4.py).  Term by term the order is fixed: inside one
+        had done before (an ulp in D's gradients; tests/test_graph_gpu.py).  Term by term the order is fixed: inside one
         term the nodes of one thread are ordered by creation, and the penalty's two contributions to a weight (through
         the first-order backward's node, then through the forward node) are ordered by data dependence."""
         for t in terms:
@@ -226,7 +234,7 @@ class TrainStep:
         d_gen = D(gen_in)                                        # running-stat update #1
         for bn in self._bns:
             bn._stat_stash = None
-        main.wait_stream(side)
+        _join_side(main, side)
         real_feat.record_stream(main)
         content = ops.l1_mean(fake_feat, real_feat)
         fake_term = ops.mean(d_gen)
@@ -266,7 +274,7 @@ class TrainStep:
         self._mark('G bwd done (main)')
         self._mark('wgrads done (wgrad stream)', side)
         main.wait_stream(dside)
-        main.wait_stream(side)
+        _join_side(main, side)
         for t in (loss_D, gp):
             t.record_stream(main)
         self._exchange_start('D')
@@ -301,7 +309,7 @@ class TrainStep:
         pixel = ops.l1_mean(gen_hr, imgs_hr)
         early = os.environ.get('SRHIP_LATE_JOIN', '1') != '1' and side is not None     # A/B knob (old order)
         if early:
-            torch.cuda.current_stream().wait_stream(side)
+            _join_side(torch.cuda.current_stream(), side)
         fake_feat = F(gen_hr)
         stash = []
         for bn in self._bns:
@@ -316,7 +324,7 @@ class TrainStep:
             with torch.no_grad():
                 real_feat = F(imgs_hr)
         else:
-            torch.cuda.current_stream().wait_stream(side)
+            _join_side(torch.cuda.current_stream(), side)
             real_feat.record_stream(torch.cuda.current_stream())   # allocated in the side stream's pool, read here
         content = ops.l1_mean(fake_feat, real_feat)
         loss_gan = -ops.mean(d_gen)
@@ -403,7 +411,7 @@ class TrainStep:
             self._mark('D bwd done (D stream)', dside)
             self._mark('wgrads done (wgrad stream)', side)
             main.wait_stream(dside)
-            main.wait_stream(side)
+            _join_side(main, side)
             for t in (loss_D, gp):
                 t.record_stream(main)
         else:
@@ -456,7 +464,8 @@ class TrainStep:
         with ops.direct_param_grads(side, group=self.wgrad_group):   # wgrad kernels accumulate straight into the gradient arenas
             out = self._compute(imgs_lr, imgs_hr, alpha)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)     # all weight gradients landed before the update
+            _join_side(torch.cuda.current_stream(), side)     # all weight gradients landed before the update
+        assert not ops._state.pending, 'weight gradients still waiting for a partner at the optimiser step'
         return out
 
     def _capture(self, imgs_lr, imgs_hr, alpha):

@@ -46,7 +46,7 @@ def test_graph_replay_is_independent_of_host_syncs_and_tracks_eager():
     # No warm-up run and no fresh process needed: TrainStep backpropagates loss_D term by term, which pins the order in
     # which the four contributions to a discriminator weight are added (train_step._backward_terms; before that the
     # order followed autograd's two per-thread node counters and with them the process's history -- an ulp in D's
-    # gradients between graph and eager whenever other autograd work had run first, tools/check_graph4.py).
+    # gradients between graph and eager whenever other autograd work had run first, the round-2 probe of the same name, git history).
     iters = 52
     sync_at = {1, 2} | set(range(7, iters, 7))
     synced_s, synced_w = _run(True, iters, sync_at)

@@ -108,7 +108,11 @@ def _check_first_iteration_gradients(label, grads, ograds, scale, lr_side, batch
           'itself G %.3e (%s) D %.3e (%s); fp32-class bars G %.3e D %.3e'
           % (label, sg, kg, sd, kd, fg, fkg, fd, fkd, rg, rkg, rd, rkd, g_bar, d_bar))
     assert fg < g_bar and fd < d_bar, ('exact-fp32 mode', fg, fkg, g_bar, fd, fkd, d_bar)
-    assert sg < 2e-2 and sd < 5e-2, ('split-bf16', sg, kg, sd, kd)
+    # regression bars close to the measured values (x8: 1.5e-2 / 3.7e-2, x9: 9.6e-3 / 2.2e-2 -- single draws of a
+    # chaotic quantity, +-20 % between builds, hence ~1.35x and not tighter): further precision loss at these scales is caught,
+    # and grad_score(verbose=True) above has printed the five worst tensors of each network
+    reg_g, reg_d = {8: (2e-2, 5e-2), 9: (1.3e-2, 3e-2)}.get(scale, (2e-2, 5e-2))
+    assert sg < reg_g and sd < reg_d, ('split-bf16', sg, kg, sd, kd, reg_g, reg_d)
 
 
 @pytest.mark.parametrize('scale,lr_side', [(2, 108), (3, 72), (8, 27), (9, 24)])
