@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   static_assert(3 * STG_B <= PATCH_B && STG_B <= BSTAGE_B, "epilogue staging must fit the released buffers");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
   __shared__ int pix_tab[128];                      // lane-row -> (orow << 16 | ocol)
+  __shared__ unsigned rel_tab[128];                 // lane-row -> byte offset of its pixel inside the destination, relative to the tile's
+                                                    // first pixel (dead rows: out of range): the epilogue adds one per-tile base
   __shared__ __attribute__((aligned(16))) float bias_s[512];   // the bias vector: the epilogue must not issue global loads of its own
                                                     // (hipcc would wait vmcnt(0) for them and serialise the stores behind each other)
 
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int pr_, pc_;
     patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
     pix_tab[tid] = (pr_ << 16) | pc_;
+    rel_tab[tid] = pr_ < pg.PH ? (unsigned)((pr_ * g.Wd + pc_) * g.ldd) * 4u : F_OOB;
   }
   if ((EPI >= 0 ? EPI : g.flags) & SRHIP_EPI_BIAS)
     for (int i = tid; i < g.K; i += 256) bias_s[i] = bias[i];
@@ -379,6 +382,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int ln = lane;                                      // opaque: the per-pass addresses are recomputed per tile, not kept in registers
     asm volatile("" : "+v"(ln));
     const int l31e = ln & 31, khe = ln >> 5;
+    // per tile and lane: this lane always serves the same four channels (cq) and the row (i * 64 + lane) / QPRW of a pass
+    const int cq = ln & (QPRW - 1), rsub = ln / QPRW;
+    const int n = t.n0 + wn * WTN + cq * 4;
+    const bool nok = n < g.K;
+    const int ns = nok ? n : 0;
+    const unsigned tile_base = (unsigned)(((t.img * g.Hd + t.oh0) * g.Wd + t.ow0) * g.ldd + n) * 4u;
+    const bool interior = t.oh0 + pg.PH <= g.OH && t.ow0 + pg.PW <= g.OW;      // block-uniform: no per-row bound checks
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (flags & SRHIP_EPI_BIAS) bb = *reinterpret_cast<const float4*>(bias_s + ns);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int tt = p >> 1, rb = (p & 1) * 8;
@@ -389,18 +401,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < NRD; ++i) {
-        const int idx = i * 64 + ln;
-        const int row = idx / QPRW, cq = idx - row * QPRW;
+        const int row = i * (64 / QPRW) + rsub;
         float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
-        const int pt = pix_tab[wm * WTM + tt * 32 + (p & 1) * 16 + row];
-        const int orow = pt >> 16, ocol = pt & 0xffff;
-        const int oh = t.oh0 + orow, ow = t.ow0 + ocol;
-        const int n = t.n0 + wn * WTN + cq * 4;
-        const bool ok = orow < pg.PH && oh < g.OH && ow < g.OW && n < g.K;
-        const int dpix = ok ? (t.img * g.Hd + oh) * g.Wd + ow : 0;
-        const int ns = ok ? n : 0;
+        const int rr = wm * WTM + tt * 32 + (p & 1) * 16 + row;
+        const unsigned rel = rel_tab[rr];
+        bool ok = nok && rel < F_OOB;
+        if (!interior) {
+          const int pt = pix_tab[rr];
+          ok = ok && t.oh0 + (pt >> 16) < g.OH && t.ow0 + (pt & 0xffff) < g.OW;
+        }
+        const unsigned doff = ok ? tile_base + rel : 0u;        // byte offset of (pixel, n) in dst (and in actmask: same geometry)
         if (flags & SRHIP_EPI_BIAS) {
-          const float4 bb = *reinterpret_cast<const float4*>(bias_s + ns);
           v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
         }
         if (flags & SRHIP_EPI_LRELU) {
@@ -410,17 +421,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
           v.w = v.w > 0.f ? v.w : v.w * g.slope;
         }
         if (flags & SRHIP_EPI_ACTMASK) {
-          const float4 a4 = *reinterpret_cast<const float4*>(actmask + (size_t)dpix * g.ldd + ns);
+          const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(actmask) + doff);
           v.x = a4.x > 0.f ? v.x : v.x * g.slope;
           v.y = a4.y > 0.f ? v.y : v.y * g.slope;
           v.z = a4.z > 0.f ? v.z : v.z * g.slope;
           v.w = a4.w > 0.f ? v.w : v.w * g.slope;
         }
         if (flags & SRHIP_EPI_RESIDUAL) {
+          const unsigned dpix = (doff >> 2) / (unsigned)g.ldd;      // (rare epilogue: the residual has its own row stride)
           const float4 r4 = *reinterpret_cast<const float4*>(residual + (size_t)dpix * g.ldr + ns);
           v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
-        const unsigned eoff = (ok && !(ABL & 1)) ? (unsigned)(dpix * g.ldd + n) * 4u : F_OOB + ((ABL & 1) ? 16u * (unsigned)(p * NRD + i) : 0u);
+        const unsigned eoff = (ok && !(ABL & 1)) ? doff : F_OOB + ((ABL & 1) ? 16u * (unsigned)(p * NRD + i) : 0u);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
