@@ -391,26 +391,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const bool interior = t.oh0 + pg.PH <= g.OH && t.ow0 + pg.PW <= g.OW;      // block-uniform: no per-row bound checks
     float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (flags & SRHIP_EPI_BIAS) bb = *reinterpret_cast<const float4*>(bias_s + ns);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int tt = p >> 1, rb = (p & 1) * 8;
-#pragma unroll
-      for (int u = 0; u < TN; ++u)
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // destination offsets of one pass (and the validity of each store)
+    auto pass_offsets = [&](int p, unsigned (&doff)[NRD], bool (&okv)[NRD]) {
 #pragma unroll
       for (int i = 0; i < NRD; ++i) {
-        const int row = i * (64 / QPRW) + rsub;
-        float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
-        const int rr = wm * WTM + tt * 32 + (p & 1) * 16 + row;
+        const int rr = wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + i * (64 / QPRW) + rsub;
         const unsigned rel = rel_tab[rr];
         bool ok = nok && rel < F_OOB;
         if (!interior) {
           const int pt = pix_tab[rr];
           ok = ok && t.oh0 + (pt >> 16) < g.OH && t.ow0 + (pt & 0xffff) < g.OW;
         }
-        const unsigned doff = ok ? tile_base + rel : 0u;        // byte offset of (pixel, n) in dst (and in actmask: same geometry)
+        okv[i] = ok;
+        doff[i] = ok ? tile_base + rel : 0u;            // byte offset of (pixel, n) in dst (and in actmask: same geometry)
+      }
+    };
+    // The activation mask of pass p + 1 is fetched BEFORE the stores of pass p are issued: the memory pipeline retires loads and
+    // stores in order, so a load issued behind a pass's stores cannot return before they have completed -- inside the training
+    // step, with three streams on the chip, that chained four store latencies per tile (dgrad 64 -> 256: 135 us in the step).
+    float4 am[2][NRD];
+    unsigned doffs[2][NRD];
+    bool oks[2][NRD];
+    pass_offsets(0, doffs[0], oks[0]);
+    if (flags & SRHIP_EPI_ACTMASK) {
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) am[0][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(actmask) + doffs[0][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int tt = p >> 1, rb = (p & 1) * 8, cur = p & 1, nx = cur ^ 1;
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
+      if (p < 3) {
+        pass_offsets(p + 1, doffs[nx], oks[nx]);
+        if (flags & SRHIP_EPI_ACTMASK) {
+#pragma unroll
+          for (int i = 0; i < NRD; ++i) am[nx][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(actmask) + doffs[nx][i]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        const int row = i * (64 / QPRW) + rsub;
+        float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+        const unsigned doff = doffs[cur][i];
+        const bool ok = oks[cur][i];
         if (flags & SRHIP_EPI_BIAS) {
           v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
         }
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
           v.w = v.w > 0.f ? v.w : v.w * g.slope;
         }
         if (flags & SRHIP_EPI_ACTMASK) {
-          const float4 a4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(actmask) + doff);
+          const float4 a4 = am[cur][i];
           v.x = a4.x > 0.f ? v.x : v.x * g.slope;
           v.y = a4.y > 0.f ? v.y : v.y * g.slope;
           v.z = a4.z > 0.f ? v.z : v.z * g.slope;
