@@ -288,17 +288,55 @@ __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f}
 
 
 // epilogue of one float4 of output (4 consecutive channels n.. of destination pixel dpix)
-__device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, const FastGeom& g,
-                                       const float* __restrict__ bias, const float* __restrict__ residual,
-                                       const float* __restrict__ rowscale, const float* __restrict__ actmask,
-                                       float* __restrict__ dst) {
+// Round 4: the epilogue of a tile row group is TWO loops -- every global operand of its NRD output quads is fetched first
+// (epi_fetch), then the arithmetic and the stores follow (epi_finish).  Loads and stores retire in order on this memory pipeline:
+// with one fused "load, wait, store" per quad, hipcc's wait for quad k's operands also waited for quad k-1's store to complete
+// (8 chained store latencies per wave and tile in the residual / activation-mask / row-scale epilogues, worst inside the step
+// where three streams share the memory system).  Same operations in the same order per element: results unchanged.
+struct EpiOps {
+  float4 bb, a4, r4, p4;
+  float rsc;
+};
+__device__ inline EpiOps epi_fetch(size_t dpix, int n, int flags, const FastGeom& g, const float* __restrict__ bias,
+                                   const float* __restrict__ residual, const float* __restrict__ rowscale,
+                                   const float* __restrict__ actmask, const float* __restrict__ dst, bool accumulate) {
+  EpiOps o;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (real branches: written as selects, hipcc turns a run-time-flagged load into a load through a pointer to a zero in scratch)
+  o.rsc = 1.f;
+  o.bb = z;
+  o.a4 = z;
+  o.r4 = z;
   if (flags & SRHIP_EPI_ROWSCALE) {
-    const float rsc = rowscale[dpix];
-    v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+    asm volatile("" ::: "memory");
+    o.rsc = rowscale[dpix];
   }
   if (flags & SRHIP_EPI_BIAS) {
-    const float4 bb = *reinterpret_cast<const float4*>(bias + n);
-    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    asm volatile("" ::: "memory");
+    o.bb = *reinterpret_cast<const float4*>(bias + n);
+  }
+  if (flags & SRHIP_EPI_ACTMASK) {
+    asm volatile("" ::: "memory");
+    o.a4 = *reinterpret_cast<const float4*>(actmask + dpix * g.ldd + n);
+  }
+  if (flags & SRHIP_EPI_RESIDUAL) {
+    asm volatile("" ::: "memory");
+    o.r4 = *reinterpret_cast<const float4*>(residual + dpix * g.ldr + n);
+  }
+  o.p4 = z;
+  if (accumulate) {                                   // a real branch: as a select hipcc loads through a pointer to a zero in scratch
+    asm volatile("" ::: "memory");
+    o.p4 = *reinterpret_cast<const float4*>(dst + dpix * g.ldd + n);
+  }
+  return o;
+}
+__device__ inline void epi_finish(float4 v, const EpiOps& e, size_t dpix, int n, int flags, const FastGeom& g, float* __restrict__ dst,
+                                  bool accumulate) {
+  if (flags & SRHIP_EPI_ROWSCALE) {
+    v.x *= e.rsc; v.y *= e.rsc; v.z *= e.rsc; v.w *= e.rsc;
+  }
+  if (flags & SRHIP_EPI_BIAS) {
+    v.x += e.bb.x; v.y += e.bb.y; v.z += e.bb.z; v.w += e.bb.w;
   }
   if (flags & SRHIP_EPI_LRELU) {
     v.x = v.x > 0.f ? v.x : v.x * g.slope;
@@ -307,20 +345,17 @@ __device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, 
     v.w = v.w > 0.f ? v.w : v.w * g.slope;
   }
   if (flags & SRHIP_EPI_ACTMASK) {
-    const float4 a4 = *reinterpret_cast<const float4*>(actmask + dpix * g.ldd + n);
-    v.x = a4.x > 0.f ? v.x : v.x * g.slope;
-    v.y = a4.y > 0.f ? v.y : v.y * g.slope;
-    v.z = a4.z > 0.f ? v.z : v.z * g.slope;
-    v.w = a4.w > 0.f ? v.w : v.w * g.slope;
+    v.x = e.a4.x > 0.f ? v.x : v.x * g.slope;
+    v.y = e.a4.y > 0.f ? v.y : v.y * g.slope;
+    v.z = e.a4.z > 0.f ? v.z : v.z * g.slope;
+    v.w = e.a4.w > 0.f ? v.w : v.w * g.slope;
   }
   if (flags & SRHIP_EPI_RESIDUAL) {
-    const float4 r4 = *reinterpret_cast<const float4*>(residual + dpix * g.ldr + n);
-    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+    v.x += e.r4.x; v.y += e.r4.y; v.z += e.r4.z; v.w += e.r4.w;
   }
   float4* o = reinterpret_cast<float4*>(dst + dpix * g.ldd + n);
-  if (g.accumulate) {
-    const float4 p4 = *o;
-    v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+  if (accumulate) {
+    v.x += e.p4.x; v.y += e.p4.y; v.z += e.p4.z; v.w += e.p4.w;
   }
   // Conv outputs are streamed out with the non-temporal hint: nothing in this kernel reads them back, and keeping them
   // out of the L2's way is worth 3-4 % on the 64 -> 256 fprop (95.6 MB written) and 0.4 % on the step.
@@ -333,7 +368,16 @@ __device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, 
   __builtin_nontemporal_store(v.z, &o->z);
   __builtin_nontemporal_store(v.w, &o->w);
 }
+// one output quad, fetch and finish together (kernels whose epilogue is not a row-group loop)
+__device__ inline void epi_apply_store(float4 v, size_t dpix, int n, int flags, const FastGeom& g,
+                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                       const float* __restrict__ rowscale, const float* __restrict__ actmask,
+                                       float* __restrict__ dst) {
+  const EpiOps e = epi_fetch(dpix, n, flags, g, bias, residual, rowscale, actmask, dst, g.accumulate != 0);
+  epi_finish(v, e, dpix, n, flags, g, dst, g.accumulate != 0);
+}
 
+// ================================================================================================ //
 template <int BM, int BN, int EPI, int MATH>
 __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restrict__ src, const float* __restrict__ wt,
                                                              const float* __restrict__ bias,
@@ -582,23 +626,38 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + u * 32 + l31] = acc[t][u][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private region: no block barrier needed
+    constexpr int EB = NRD < 4 ? NRD : 4;               // quads per fetch / finish batch
 #pragma unroll
-    for (int i = 0; i < NRD; ++i) {
-      const int idx = i * 64 + lane;
-      const int row = idx / QPRW, cq = idx - row * QPRW;
-      float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
-      const int m = m0 + wm * WTM + t * 32 + row;
-      const int n = n0 + wn * WTN + cq * 4;
-      if (m >= g.M || n >= g.K) continue;
-      size_t dpix = (size_t)m;
-      if (!g.dst_identity) {
-        const int nimg = m / OHOW;
-        const int rem = m - nimg * OHOW;
-        const int oh = rem / g.OW;
-        const int ow = rem - oh * g.OW;
-        dpix = ((size_t)nimg * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
+    for (int i0 = 0; i0 < NRD; i0 += EB) {
+      float4 vq[EB];
+      EpiOps eo[EB];
+      unsigned dpx[EB];                                   // pixel index (< 2^31: checked on the host side)
+      int nq[EB];
+      bool okq[EB];
+#pragma unroll
+      for (int j = 0; j < EB; ++j) {                    // every global operand of the batch first ...
+        const int idx = (i0 + j) * 64 + lane;
+        const int row = idx / QPRW, cq = idx - row * QPRW;
+        vq[j] = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+        const int m = m0 + wm * WTM + t * 32 + row;
+        nq[j] = n0 + wn * WTN + cq * 4;
+        okq[j] = m < g.M && nq[j] < g.K;
+        size_t dpix = (size_t)(okq[j] ? m : 0);
+        if (!g.dst_identity) {
+          const int mm = okq[j] ? m : 0;
+          const int nimg = mm / OHOW;
+          const int rem = mm - nimg * OHOW;
+          const int oh = rem / g.OW;
+          const int ow = rem - oh * g.OW;
+          dpix = ((size_t)nimg * g.Hd + (oh * g.dsd + g.ph)) * g.Wd + (ow * g.dsd + g.pw);
+        }
+        dpx[j] = (unsigned)dpix;
+        if (!okq[j]) nq[j] = 0;
+        eo[j] = epi_fetch(dpix, nq[j], flags, g, bias, residual, rowscale, actmask, dst, EPI < 0 && g.accumulate != 0);
       }
-      epi_apply_store(v, dpix, n, flags, g, bias, residual, rowscale, actmask, dst);
+#pragma unroll
+      for (int j = 0; j < EB; ++j)                      // ... then the arithmetic and the stores (see epi_fetch)
+        if (okq[j]) epi_finish(vq[j], eo[j], dpx[j], nq[j], flags, g, dst, EPI < 0 && g.accumulate != 0);
     }
     if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the region is rewritten
   }
@@ -828,19 +887,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
       for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + u * 32 + l31] = acc[t][u][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int EB = NRD < 4 ? NRD : 4;               // quads per fetch / finish batch (register budget: 17 values per quad at most)
 #pragma unroll
-    for (int i = 0; i < NRD; ++i) {
-      const int idx = i * 64 + lane;
-      const int row = idx / QPRW, cq = idx - row * QPRW;
-      const float4 v = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
-      const int r = wm * WTM + t * 32 + row;
-      const int pt = pix_tab[r];
-      const int orow = pt >> 16, ocol = pt & 0xffff;
-      const int oh = oh0 + orow, ow = ow0 + ocol;
-      const int n = n0 + wn * WTN + cq * 4;
-      if (orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K) continue;
-      const size_t dpix = ((size_t)img * g.Hd + oh) * g.Wd + ow;
-      epi_apply_store(v, dpix, n, flags, g, bias, residual, nullptr, actmask, dst);
+    for (int i0 = 0; i0 < NRD; i0 += EB) {
+      float4 vq[EB];
+      EpiOps eo[EB];
+      unsigned dpx[EB];                                   // pixel index (< 2^31: checked on the host side)
+      int nq[EB];
+      bool okq[EB];
+#pragma unroll
+      for (int j = 0; j < EB; ++j) {                    // every global operand of the batch first (epi_fetch) ...
+        const int idx = (i0 + j) * 64 + lane;
+        const int row = idx / QPRW, cq = idx - row * QPRW;
+        vq[j] = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+        const int r = wm * WTM + t * 32 + row;
+        const int pt = pix_tab[r];
+        const int orow = pt >> 16, ocol = pt & 0xffff;
+        const int oh = oh0 + orow, ow = ow0 + ocol;
+        const int n = n0 + wn * WTN + cq * 4;
+        okq[j] = !(orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K);
+        dpx[j] = okq[j] ? (unsigned)((img * g.Hd + oh) * g.Wd + ow) : 0u;
+        nq[j] = okq[j] ? n : 0;
+        eo[j] = epi_fetch(dpx[j], nq[j], flags, g, bias, residual, nullptr, actmask, dst, false);   // (the patch path never accumulates)
+      }
+#pragma unroll
+      for (int j = 0; j < EB; ++j)                      // ... then the arithmetic and the stores
+        if (okq[j]) epi_finish(vq[j], eo[j], dpx[j], nq[j], flags, g, dst, false);
     }
     if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }

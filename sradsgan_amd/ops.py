@@ -32,6 +32,8 @@ class _State:
     capturing = False               # a stream capture is being recorded (TrainStep._capture): side-stream forks go through torch events
     wgrad_group = 1                 # weight gradients of one shape launched together (srhip_conv2d_wgrad_multi); 1 = off
     pending = None                  # shape key -> [(x, dy, gw, gb, stride, pad)] waiting for partners (direct_param_grads mode)
+    held = None                     # [[event | None, [tensors]]]: operands of side-stream kernels, see _hold_for_side
+    hold_n = 0
 
 
 _state = _State()
@@ -78,14 +80,49 @@ def direct_param_grads(side_stream=None, group=1):
     them: one wgrad launch per conv instead of wgrad + one `grad += new` launch per parameter
     (~600 tiny launches per step).  Only valid when every such parameter already owns a dense .grad
     and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
-    prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending)
+    prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held)
     _state.direct_grads, _state.wgrad_stream = True, side_stream
-    _state.wgrad_group, _state.pending = (group if side_stream is not None else 1), {}
+    _state.wgrad_group, _state.pending, _state.held = (group if side_stream is not None else 1), {}, [[None, []]]
     try:
         yield
         flush_pending_wgrads()
     finally:
-        _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending = prev
+        _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held = prev
+
+
+def _hold_for_side(side, *tensors):
+    """Keeps `tensors` (operands of a kernel just launched on the side stream) referenced until the side stream has got past
+    that kernel.  record_stream() protects their MEMORY; this protects their CONTENTS: autograd's input buffer adds later
+    contributions IN PLACE into a gradient it holds the only reference to (torch/csrc/autograd/input_buffer.cpp,
+    use_count() == 1), on the main stream, which the side stream may trail by a millisecond.  A gradient a backward hands
+    back unchanged (the skip of the attention tail, the residual of a conv, the second consumer of a torch add) while its
+    weight-gradient kernel still waits on the side stream was modified under that kernel: ResGroup tail conv gradients
+    off by 10-30 % whenever the side stream lagged (tests/test_model_gpu.py, first-step test with two pool streams).
+    With a second reference alive the engine allocates the sum instead.  Every 8th launch closes the open group with an
+    event on the side stream; groups whose event has completed are dropped, so the extra lifetime is the lag itself."""
+    h = _state.held
+    if h is None:
+        return
+    h[-1][1].extend(t for t in tensors if t is not None)
+    _state.hold_n += 1
+    if _state.hold_n % 8 or _state.capturing:
+        return
+    ev = torch.cuda.Event()
+    ev.record(side)
+    h[-1][0] = ev
+    while len(h) and h[0][0] is not None and h[0][0].query():
+        h.pop(0)
+    h.append([None, []])
+
+
+def _passed_through(g):
+    """Marks an incoming gradient that a backward returns UNCHANGED as the gradient of one of its inputs (see
+    _hold_for_side: the engine must not add into it in place while a side-stream kernel reads it).  The kernels' own launch
+    sites hold their operands already; this covers the window in which a grouped weight gradient has been flushed by a
+    partner before this backward returns."""
+    if _state.wgrad_stream is not None and _state.held is not None and g is not None:
+        _state.held[-1][1].append(g)
+    return g
 
 
 def _grad_slot(p):
@@ -459,6 +496,7 @@ def _flush_key(key):
     for it in items:
         it[0].record_stream(side)
         it[1].record_stream(side)
+        _hold_for_side(side, it[1])
 
 
 def flush_pending_wgrads():
@@ -509,6 +547,7 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
         for t in (x, dy, xrowscale, xchanscale):
             if t is not None:
                 t.record_stream(side)
+        _hold_for_side(side, dy)
         return None, None
     if gw is not None and (not want_b or gb is not None):
         # Shapes the accumulating kernel does not take (the 3- and 2-channel convs, the 64 -> 3 tail conv): add in program order
@@ -532,6 +571,7 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
         for t in (x, dy, xrowscale, xchanscale):
             if t is not None:
                 t.record_stream(side)
+        _hold_for_side(side, dy)
         return None, None
     return conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale)
 
@@ -568,6 +608,7 @@ def _wgrad_act_direct(w, b, x, dy, y, slope, stride, pad):
     if side is not None:
         for t in (x, dy, y):
             t.record_stream(side)
+        _hold_for_side(side, dy)
     return True
 
 
@@ -658,7 +699,7 @@ class _ConvFwd(Function):
             dw, db = _ConvWgrad.apply(x, g, tuple(w.shape), ctx.stride, ctx.pad, want_b)
         elif want_b:
             db = _ColSum.apply(g)
-        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        dres = _passed_through(dy) if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None
 
 
@@ -862,7 +903,7 @@ class _AttentionTail(Function):
         g = nhwc(g)
         du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_bias,
                                                        _skip_param_grads())
-        return du, g, dfc1, dfc2, dw7, dwc, dbc
+        return du, _passed_through(g), dfc1, dfc2, dw7, dwc, dbc
 
 
 class _RabBlock(Function):
@@ -1234,7 +1275,7 @@ class _SgamCore(Function):
         _hip.check(lib.srhip_sgam_flash_bwd(_p(dy), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(gam), _p(dq), _p(dk), _p(dv),
                                             _p(dgam), acc, _p(ws), ws.numel() * 4, n, h * w, q.shape[1], c, _stream()),
                    'sgam_flash_bwd')
-        return dy, dq, dk, dv, (None if (skip or acc) else dgam.view(gamma.shape))
+        return _passed_through(dy), dq, dk, dv, (None if (skip or acc) else dgam.view(gamma.shape))
 
 
 def sgam(x, q, k, v, gamma):

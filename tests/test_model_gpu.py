@@ -485,3 +485,53 @@ def test_first_step_of_a_model_does_not_depend_on_allocator_history(scale, batch
     assert all(bool(torch.isfinite(g).all()) for g in g1 + g2)
     assert torch.equal(s1, s2)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+@pytest.mark.parametrize('op', ['attention_tail', 'conv_residual'])
+def test_weight_gradient_on_a_lagging_side_stream_reads_the_gradient_it_was_launched_with(op):
+    """The attention tail hands its incoming gradient back unchanged as the gradient of `skip`, a conv with a fused residual
+    hands it back as the residual's; both launch a weight-gradient kernel that reads the same tensor on the side stream.
+    Autograd's input buffer adds a later contribution to `skip` IN PLACE into a gradient it holds the only reference to -- on
+    the main stream.  With the side stream held up (here by a few large matrix products queued on it before the backward; in
+    the step by whatever else the chip is doing) the kernel read g + the other branch's gradient: weight gradients of the
+    ResGroup tail convs off by 10-30 %, at random.  ops._hold_for_side keeps a second reference until the side stream has
+    passed the kernel, so the engine allocates the sum instead.  Same inputs with the weight gradients in line (no side
+    stream) and on a lagging side stream: identical parameter gradients."""
+    from sradsgan_amd import ops
+    n, h, w = 4, 54, 54
+    g = torch.Generator().manual_seed(41)
+
+    def cl(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).to(DEV).contiguous(memory_format=torch.channels_last)
+
+    x0, u0, c1, c2 = cl(n, 64, h, w), cl(n, 64, h, w), cl(n, 64, h, w), cl(n, 64, h, w)
+    shapes = {'attention_tail': [(4, 64, 1, 1), (64, 4, 1, 1), (1, 2, 7, 7), (64, 64, 1, 1), (64,)],
+              'conv_residual': [(64, 64, 3, 3), (64,)]}[op]
+    init = [(torch.randn(*s, generator=g) * 0.1).to(DEV) for s in shapes]
+    big = torch.randn(8192, 8192, device=DEV)
+
+    def run(side):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        for p in ps:
+            p.grad = torch.zeros_like(p)
+        x, u = x0.clone().requires_grad_(True), u0.clone().requires_grad_(True)
+        skip = x * 1.0
+        y2 = skip * 2.0                    # created before the op below: its gradient reaches skip's buffer AFTER the op's
+        y1 = ops.attention_tail(u, skip, *ps) if op == 'attention_tail' else ops.conv2d(u, ps[0], ps[1], 1, 1, None, skip)
+        loss = (y1 * c1).sum() + (y2 * c2).sum()
+        torch.cuda.synchronize()
+        if side is not None:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    big @ big              # ~60 ms of work in front of the weight-gradient kernels
+        with ops.direct_param_grads(side):
+            loss.backward()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in ps] + [x.grad.clone(), u.grad.clone()]
+
+    ref = run(None)
+    got = run(torch.cuda.Stream())
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (op, i, float((a - b).abs().max()), float(a.abs().max()))
