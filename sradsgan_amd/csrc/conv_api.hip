@@ -55,6 +55,8 @@ __global__ void pack_batched_kernel(const PackEntry* __restrict__ tab) {
 namespace srhip {
 extern int g_fast_cfg;
 extern int g_wgrad_cfg;
+extern int g_rowtap_addr;
+extern int g_rowtap_pipe;
 extern int g_fast_dynlds;
 extern int g_fast_ablate;
 extern int g_conv_math;
@@ -159,6 +161,14 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 7) {
     g_tail_dbg = value;
+    return SRHIP_OK;
+  }
+  if (key == 8) {
+    g_rowtap_addr = value;
+    return SRHIP_OK;
+  }
+  if (key == 9) {
+    g_rowtap_pipe = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

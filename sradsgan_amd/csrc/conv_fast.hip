@@ -1475,8 +1475,8 @@ struct WgradBatch {
   int nprob, bpp;
 };
 
-template <int BM, int CIS, bool SPLIT = true>     // SPLIT false: one bf16 product per multiply (SRHIP_MATH_HALF)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void wgrad_rowtap_kernel(
+template <int BM, int CIS, bool SPLIT = true, int ADDR = 1, bool PIPE = false>     // SPLIT false: one bf16 product per multiply (SRHIP_MATH_HALF)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 2 : 3))) void wgrad_rowtap_kernel(
     const float* __restrict__ x_, const float* __restrict__ dy_, float* __restrict__ partial_,
     float* __restrict__ bias_partial_, WgradGeom g, int nseg, int chunks_per_split, int tail_rem, WgradBatch bt) {
   const float* x = x_;
@@ -1511,7 +1511,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   constexpr int NBT = B_B / 1024;                   // B pieces per chunk, dealt to the waves in order
   constexpr int RPA = 1024 / (BM * 4), RPB = 1024 / (CIS * 4);   // pixel rows per piece
   constexpr int EPI_B = 4 * 32 * 32 * 4;
-  constexpr int LDS_B = 3 * STAGE_B > EPI_B ? 3 * STAGE_B : EPI_B;
+  constexpr int NSLOT = PIPE ? 5 : 3;               // PIPE: two blocks per CU (registers), so the ring can be five chunks deep
+  constexpr int LDS_B = NSLOT * STAGE_B > EPI_B ? NSLOT * STAGE_B : EPI_B;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1641,6 +1642,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
       }
     }
   };
+  // ADDR 1 (round 4): the same DMAs with the chunk's position as the instruction's SCALAR offset.  The form above rebuilds every
+  // lane's byte offset per chunk (64-bit pixel arithmetic, selects lowered to exec-mask branches: ~90 VALU instructions and 16
+  // branches per chunk and wave in front of the 18 MFMAs).  Here a lane keeps constant offsets relative to the chunk's first
+  // pixel, the chunk's first pixel goes into the buffer instruction's soffset (tensors < 2 GiB, so offset + soffset cannot wrap
+  // and a dead lane's 0x80000000 stays out of range whichever way the range check counts soffset), and validity is one
+  // compare against a scalar limit.  The x descriptor starts one image row + one pixel BEFORE the tensor so that the halo
+  // pixel (-1) of row -1 has offset 0; lanes that would read there are dead lanes.  Same bytes into the same LDS places.
+  const unsigned x_shift = (unsigned)(g.W + 1) * (unsigned)g.ldx * 4u;
+  __amdgpu_buffer_rsrc_t rs_xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) - (size_t)(g.W + 1) * g.ldx, 0, g.x_bytes + x_shift, 0x00020000);
+  unsigned a_full[NA], a_tailv[NA], a_tailA[NA];     // dy: full chunk / tail chunk (both rows live) / tail chunk (row B dead)
+  int a_j[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int j = (wave * NA + i) * RPA + a_rsub;
+    a_j[i] = j;
+    a_full[i] = a_colok ? (unsigned)(j * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
+    const int half = j >> 3, jj = j & 7;
+    a_tailv[i] = (a_colok && jj < tail_rem) ? (unsigned)((half * g.Wo + jj) * g.ldy + m0 + a_col * 4) * 4u : F_OOB;
+    a_tailA[i] = half ? F_OOB : a_tailv[i];
+  }
+  constexpr int NBI = NBT / 4 + 1;
+  unsigned b_full[NBI], b_tailv[NBI];
+  int b_r[NBI], b_half[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; ++i) {
+    const int r = (b_first + i) * RPB + b_rsub;
+    b_r[i] = r;
+    b_full[i] = r < 18 ? (unsigned)(r * g.ldx + ci_base + b_col * 4) * 4u : F_OOB;
+    const int half = r >= 10 ? 1 : 0, ss = r - 10 * half;
+    b_half[i] = half;
+    const int wo0t = (g.Wo >> 4) * 16;
+    const bool okss = r < 20 && ss <= tail_rem && wo0t - 1 + ss >= 0;            // input column wo0 - 1 + ss inside the row
+    b_tailv[i] = okss ? (unsigned)((half * g.W + ss) * g.ldx + ci_base + b_col * 4) * 4u : F_OOB;
+  }
+  int i_row = 0;                                    // flat output row (image * Ho + row) of the chunk the next issue fetches (row A of a pair)
+  if (ADDR == 1) i_row = i_n * g.Ho + i_ho;
+  const int rows_all = g.N * g.Ho;
+  auto dma_s = [&](unsigned voff, unsigned soff, __amdgpu_buffer_rsrc_t r, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(dst) : "memory");
+  };
+  auto issue_s = [&](int slot) {
+    const unsigned adst = a_dst + slot * STAGE_B, bdst = b_dst + slot * STAGE_B;
+    if (tail_rem > 0 && i_seg == 2 * q) {           // both rows' tails
+      const int wo0 = q * 16;
+      const bool liveB = i_row + 1 < rows_all;
+      const int hoB = i_ho + 1 < g.Ho ? i_ho + 1 : 0;
+      const int hiA = i_ho - 1 + kh, hiB = hoB - 1 + kh;
+      const bool okA = hiA >= 0 && hiA < g.H, okB = liveB && hiB >= 0 && hiB < g.H;
+      const unsigned sa = (unsigned)(i_row * g.Wo + wo0) * (unsigned)g.ldy * 4u;
+      const unsigned sb = (unsigned)((i_row + kh) * g.W + wo0) * (unsigned)g.ldx * 4u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma_s(liveB ? a_tailv[i] : a_tailA[i], sa, rs_y, adst + i * 1024);
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+        if (i < nb) dma_s((b_half[i] ? okB : okA) ? b_tailv[i] : F_OOB, sb, rs_xs, bdst + i * 1024);
+      i_seg = 0;
+      i_row += 2;
+      i_ho += 2;
+      if (i_ho >= g.Ho) i_ho -= g.Ho;
+      return;
+    }
+    const int rowB = (tail_rem > 0 && i_seg >= q) ? 1 : 0;
+    const int c_row = i_row + rowB;
+    int c_ho = i_ho + rowB;
+    if (c_ho >= g.Ho) c_ho -= g.Ho;
+    const bool rowlive = c_row < rows_all;
+    const int wo0 = (rowB ? i_seg - q : i_seg) * 16;
+    const int hi = c_ho - 1 + kh;
+    const bool rowok = rowlive && hi >= 0 && hi < g.H;
+    const unsigned sa = rowlive ? (unsigned)(c_row * g.Wo + wo0) * (unsigned)g.ldy * 4u : 0u;
+    const unsigned sb = rowok ? (unsigned)((c_row + kh) * g.W + wo0) * (unsigned)g.ldx * 4u : 0u;
+    const int lim_a = rowlive ? g.Wo - wo0 : 0;                       // pixel slots j < lim_a are inside the row
+    const int lo_b = rowok ? 1 - wo0 : 64;                            // staged rows lo_b <= r < hi_b are inside the input row
+    const int hi_b = g.W + 1 - wo0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma_s(a_j[i] < lim_a ? a_full[i] : F_OOB, sa, rs_y, adst + i * 1024);
+#pragma unroll
+    for (int i = 0; i < NBI; ++i)
+      if (i < nb) dma_s((b_r[i] >= lo_b && b_r[i] < hi_b) ? b_full[i] : F_OOB, sb, rs_xs, bdst + i * 1024);
+    if (tail_rem > 0) {
+      ++i_seg;
+    } else if (++i_seg == nseg) {
+      i_seg = 0;
+      ++i_row;
+      if (++i_ho == g.Ho) i_ho = 0;
+    }
+  };
   auto wait_chunk = [&](bool more) {                // this wave's pieces of the oldest chunk in flight have landed
     if (!more) {
       wait_vmcnt<0>();
@@ -1669,63 +1757,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   float bsum = 0.f;
   const bool want_bias = bias_partial != nullptr && tile_n == 0 && tid < BM;
 
-  if (nk > 0) {
-    issue(0);
-    if (nk > 1) issue(1);
-    int stage = 0, nstage = 2;
-    for (int kc = 0; kc < nk; ++kc) {
-      wait_chunk(kc + 1 < nk);
+  auto issue_any = [&](int slot) {
+    if (ADDR == 1) issue_s(slot);
+    else issue(slot);
+  };
+  struct Frags {
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+  };
+  // raw fp32 stage -> this wave's split fragments of one chunk (+ the bias column sum, taken from the raw dy rows)
+  auto convert = [&](int slot, Frags& f) {
+    const char* sb = lds + slot * STAGE_B;
+    const int b_off = (tail_rem > 0 && c_sub == 2 * q) ? b_off_tail : b_off_full;
+    if (tail_rem > 0) c_sub = c_sub == 2 * q ? 0 : c_sub + 1;
+    // A fragments: gather 8 pixels, split
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(sb + a_off + j * BM * 4 + t * 128);
+      split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), f.ah[t], f.al[t]);
+    }
+    // B: 10 staged pixels -> packed hi/lo pairs P0..P4 -> the three kw fragments (kw 1 by a 16-bit funnel shift)
+    unsigned ph[5], pl[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const float e0 = *reinterpret_cast<const float*>(sb + b_off + (2 * i) * CIS * 4);
+      const float e1 = *reinterpret_cast<const float*>(sb + b_off + (2 * i + 1) * CIS * 4);
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const bf16x2_t h = {(__bf16)e0, (__bf16)e1};
+      ph[i] = __builtin_bit_cast(unsigned, h);
+      const bf16x2_t l = {(__bf16)(e0 - __uint_as_float(ph[i] << 16)), (__bf16)(e1 - __uint_as_float(ph[i] & 0xffff0000u))};
+      pl[i] = __builtin_bit_cast(unsigned, l);
+    }
+    {
+      const u32x4 h0 = {ph[0], ph[1], ph[2], ph[3]}, l0 = {pl[0], pl[1], pl[2], pl[3]};
+      const u32x4 h2 = {ph[1], ph[2], ph[3], ph[4]}, l2 = {pl[1], pl[2], pl[3], pl[4]};
+      const u32x4 h1 = {__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
+                        __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16)};
+      const u32x4 l1 = {__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
+                        __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16)};
+      f.bh[0] = __builtin_bit_cast(bf16x8_t, h0); f.bl[0] = __builtin_bit_cast(bf16x8_t, l0);
+      f.bh[1] = __builtin_bit_cast(bf16x8_t, h1); f.bl[1] = __builtin_bit_cast(bf16x8_t, l1);
+      f.bh[2] = __builtin_bit_cast(bf16x8_t, h2); f.bl[2] = __builtin_bit_cast(bf16x8_t, l2);
+    }
+    if (want_bias) {
+      const float* col = reinterpret_cast<const float*>(sb) + tid;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += col[r * BM];
+    }
+  };
+  auto mfma_all = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < (SPLIT ? 3 : 1) * TM * TN; ++i) {
+      const int grp = SPLIT ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
+      acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? f.al[t] : f.ah[t], grp == 1 ? f.bl[u] : f.bh[u], acc[t][u], 0, 0, 0);
+    }
+  };
+  if constexpr (!PIPE) {
+    if (nk > 0) {
+      issue_any(0);
+      if (nk > 1) issue_any(1);
+      int stage = 0, nstage = 2;
+      for (int kc = 0; kc < nk; ++kc) {
+        wait_chunk(kc + 1 < nk);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kc + 2 < nk) issue_any(nstage);
+        Frags f;
+        convert(stage, f);
+        mfma_all(f);
+        stage = stage == 2 ? 0 : stage + 1;
+        nstage = nstage == 2 ? 0 : nstage + 1;
+      }
+    }
+  } else {
+    // PIPE (round 4): the conversion of chunk k + 1 and the MFMAs of chunk k are independent instruction streams of one loop body.
+    // In the form above a wave alternates a ~90-instruction gather / split phase with 18 back-to-back MFMAs, and the co-resident
+    // waves of a SIMD (same code, started together, re-synchronised by every stall) do the same phases at the same time: the
+    // ablation of round 2 found the parts ADDING UP (MFMAs 37, conversion 24, DMA 7, barrier 4.5 of 123 us).  Holding the next
+    // chunk's fragments costs 40 registers: two waves per SIMD instead of three, which pays for a five-deep operand ring.
+    constexpr int D = NSLOT - 1;                    // chunks in flight
+    const int per = NA + nb;                        // DMAs of this wave per chunk
+    auto wait_after = [&](int chunks) {             // all but the newest `chunks` chunks of this wave's DMAs have landed
+      const int n = chunks * per;
+      switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+    };
+    static_assert(NA + NBT / 4 == 3, "wait_after's cases assume 3 or 4 DMAs per wave and chunk");
+    if (nk > 0) {
+      int issued = 0;
+      for (; issued < D && issued < nk; ++issued) issue_any(issued);
+      wait_after(issued - 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kc + 2 < nk) issue(nstage);
-      const char* sb = lds + stage * STAGE_B;
-      const int b_off = (tail_rem > 0 && c_sub == 2 * q) ? b_off_tail : b_off_full;
-      if (tail_rem > 0) c_sub = c_sub == 2 * q ? 0 : c_sub + 1;
-      // A fragments: gather 8 pixels, split
-      bf16x8_t ah[TM], al[TM];
-#pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(sb + a_off + j * BM * 4 + t * 128);
-        split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), ah[t], al[t]);
+      int islot = D;
+      if (issued < nk) {
+        issue_any(islot);
+        ++issued;
+        islot = 0;
       }
-      // B: 10 staged pixels -> packed hi/lo pairs P0..P4 -> the three kw fragments (kw 1 by a 16-bit funnel shift)
-      unsigned ph[5], pl[5];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const float e0 = *reinterpret_cast<const float*>(sb + b_off + (2 * i) * CIS * 4);
-        const float e1 = *reinterpret_cast<const float*>(sb + b_off + (2 * i + 1) * CIS * 4);
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t h = {(__bf16)e0, (__bf16)e1};
-        ph[i] = __builtin_bit_cast(unsigned, h);
-        const bf16x2_t l = {(__bf16)(e0 - __uint_as_float(ph[i] << 16)), (__bf16)(e1 - __uint_as_float(ph[i] & 0xffff0000u))};
-        pl[i] = __builtin_bit_cast(unsigned, l);
+      Frags f;
+      convert(0, f);
+      int cslot = 1;
+      for (int kc = 0; kc + 1 < nk; ++kc) {
+        wait_after(issued - (kc + 2));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < nk) {
+          issue_any(islot);
+          ++issued;
+          islot = islot == NSLOT - 1 ? 0 : islot + 1;
+        }
+        Frags gnext;
+        convert(cslot, gnext);
+        mfma_all(f);
+        f = gnext;
+        cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
       }
-      bf16x8_t bh[TN], bl[TN];
-      {
-        const u32x4 h0 = {ph[0], ph[1], ph[2], ph[3]}, l0 = {pl[0], pl[1], pl[2], pl[3]};
-        const u32x4 h2 = {ph[1], ph[2], ph[3], ph[4]}, l2 = {pl[1], pl[2], pl[3], pl[4]};
-        const u32x4 h1 = {__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
-                          __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16)};
-        const u32x4 l1 = {__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
-                          __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16)};
-        bh[0] = __builtin_bit_cast(bf16x8_t, h0); bl[0] = __builtin_bit_cast(bf16x8_t, l0);
-        bh[1] = __builtin_bit_cast(bf16x8_t, h1); bl[1] = __builtin_bit_cast(bf16x8_t, l1);
-        bh[2] = __builtin_bit_cast(bf16x8_t, h2); bl[2] = __builtin_bit_cast(bf16x8_t, l2);
-      }
-#pragma unroll
-      for (int i = 0; i < (SPLIT ? 3 : 1) * TM * TN; ++i) {
-        const int grp = SPLIT ? i / (TM * TN) : 2, t = (i % (TM * TN)) / TN, u = i % TN;
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u], 0, 0, 0);
-      }
-      if (want_bias) {
-        const float* col = reinterpret_cast<const float*>(sb) + tid;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bsum += col[r * BM];
-      }
-      stage = stage == 2 ? 0 : stage + 1;
-      nstage = nstage == 2 ? 0 : nstage + 1;
+      mfma_all(f);
     }
   }
 
@@ -2367,6 +2524,8 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
 struct FastWgradPlan {
   int bm, bn, bk, nsplit, chunks_per_split;
 };
+int g_rowtap_pipe = 0; // srhip_debug_set(9, v): 1 = software-pipelined row-tap kernel (conversion of chunk k+1 beside the MFMAs of chunk k, 2 blocks / CU)
+int g_rowtap_addr = 1; // srhip_debug_set(8, v): 0 = per-lane DMA offsets of rounds 1-3 in wgrad_rowtap_kernel (A/B), 1 = scalar chunk offsets
 int g_wgrad_cfg = 0;   // experiment knob (srhip_debug_set(1, cfg)): 0 heuristic, 1: bn=64, 2: bn=128, 8: scalar split-K reduce kernels (rounds 1-3), +10: register-staged kernel
 // row-tap kernel (wgrad_rowtap_kernel): split-bf16, 3x3 stride 1 pad 1, Cin % 64 == 0, Cout % 4 == 0 (g_wgrad_cfg 7 turns it off)
 static int rowtap_ok(int cin, int cout, int kh, int kw, int stride, int pad) {   // 0: no, 1: 128 x (kh, 64 ci), 2: 64 x (kh, 128 ci)
@@ -2505,18 +2664,23 @@ int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, con
     const int tail_rem = (rem > 0 && rem <= 8 && g.Wo >= 16 && g.Ho >= 2 && g_wgrad_cfg != 9) ? rem : 0;
     const int nchunks_rt = tail_rem ? ((g.N * g.Ho + 1) / 2) * (2 * (g.Wo / 16) + 1) : g.N * g.Ho * nseg;
     const int cps = cdiv(nchunks_rt, p.nsplit);
-    if (rowtap == 1 && g_conv_math == 2)
-      hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
-    else if (rowtap == 1)
-      hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
-    else if (g_conv_math == 2)
-      hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
-    else
-      hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, x, dy, partial,
-                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});
+#define SRHIP_RT(BM_, CIS_, SP_)                                                                                         \
+  do {                                                                                                                 \
+    if (g_rowtap_pipe)                                                                                                 \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 1, true>), dim3(blocks), dim3(256), 0, st, x, dy, partial, \
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});                           \
+    else if (g_rowtap_addr)                                                                                            \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 1>), dim3(blocks), dim3(256), 0, st, x, dy, partial,     \
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});                           \
+    else                                                                                                               \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 0>), dim3(blocks), dim3(256), 0, st, x, dy, partial,     \
+                         db ? bias_partial : nullptr, g, nseg, cps, tail_rem, WgradBatch{});                           \
+  } while (0)
+    if (rowtap == 1 && g_conv_math == 2) SRHIP_RT(128, 64, false);
+    else if (rowtap == 1) SRHIP_RT(128, 64, true);
+    else if (g_conv_math == 2) SRHIP_RT(64, 128, false);
+    else SRHIP_RT(64, 128, true);
+#undef SRHIP_RT
   } else if (p.bm == 256 && p.bn == 64)
     SRHIP_LW(256, 64, 4, 1);
   else if (p.bm == 64 && p.bn == 256)
@@ -2613,14 +2777,23 @@ int fast_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const
     any_bias = any_bias || bt.bias_partial[i] != nullptr;
   }
   const int blocks = bt.bpp * nprob;
-  if (rowtap == 1 && g_conv_math == 2)
-    hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64, false>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
-  else if (rowtap == 1)
-    hipLaunchKernelGGL((wgrad_rowtap_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
-  else if (g_conv_math == 2)
-    hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128, false>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
-  else
-    hipLaunchKernelGGL((wgrad_rowtap_kernel<64, 128>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);
+#define SRHIP_RTM(BM_, CIS_, SP_)                                                                                        \
+  do {                                                                                                                 \
+    if (g_rowtap_pipe)                                                                                                 \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 1, true>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0], \
+                         bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);                               \
+    else if (g_rowtap_addr)                                                                                            \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 1>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0],  \
+                         bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);                               \
+    else                                                                                                               \
+      hipLaunchKernelGGL((wgrad_rowtap_kernel<BM_, CIS_, SP_, 0>), dim3(blocks), dim3(256), 0, st, bt.x[0], bt.dy[0],  \
+                         bt.partial[0], bt.bias_partial[0], g, nseg, cps, tail_rem, bt);                               \
+  } while (0)
+  if (rowtap == 1 && g_conv_math == 2) SRHIP_RTM(128, 64, false);
+  else if (rowtap == 1) SRHIP_RTM(128, 64, true);
+  else if (g_conv_math == 2) SRHIP_RTM(64, 128, false);
+  else SRHIP_RTM(64, 128, true);
+#undef SRHIP_RTM
   int rc = check_launch("fast_wgrad_multi");
   if (rc) return rc;
   if (launch_reduce4(nprob, bt.partial, bt.bias_partial, dw, db, ns, cout, cin, kh * kw, g.Ktot, accumulate, st))

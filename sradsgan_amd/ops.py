@@ -90,6 +90,9 @@ def direct_param_grads(side_stream=None, group=1):
         _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held = prev
 
 
+_HOLD = os.environ.get('SRHIP_HOLD', '1') == '1'      # 0: test knob, reproduces the pass-through race (tests/test_model_gpu.py)
+
+
 def _hold_for_side(side, *tensors):
     """Keeps `tensors` (operands of a kernel just launched on the side stream) referenced until the side stream has got past
     that kernel.  record_stream() protects their MEMORY; this protects their CONTENTS: autograd's input buffer adds later
@@ -101,7 +104,7 @@ def _hold_for_side(side, *tensors):
     With a second reference alive the engine allocates the sum instead.  Every 8th launch closes the open group with an
     event on the side stream; groups whose event has completed are dropped, so the extra lifetime is the lag itself."""
     h = _state.held
-    if h is None:
+    if h is None or not _HOLD:
         return
     h[-1][1].extend(t for t in tensors if t is not None)
     _state.hold_n += 1
@@ -120,7 +123,7 @@ def _passed_through(g):
     _hold_for_side: the engine must not add into it in place while a side-stream kernel reads it).  The kernels' own launch
     sites hold their operands already; this covers the window in which a grouped weight gradient has been flushed by a
     partner before this backward returns."""
-    if _state.wgrad_stream is not None and _state.held is not None and g is not None:
+    if _state.wgrad_stream is not None and _state.held is not None and g is not None and _HOLD:
         _state.held[-1][1].append(g)
     return g
 
