@@ -328,6 +328,12 @@ int srhip_bn_train_fwd(const float* x, const float* gamma, const float* beta, fl
 int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                        const float* save_invstd, float* dx, float* dgamma, float* dbeta, void* workspace,
                        size_t workspace_bytes, long rows, int c, float slope, int apply_act, void* stream);
+/* ABI 7: the same pass, and acc_gamma[c] += dgamma[c], acc_beta[c] += dbeta[c] when the pointers are not NULL (the parameters'
+ * .grad buffers: what optimizer-side accumulation of sradsgan.py:858/887 sees; one writer per channel, deterministic).      */
+int srhip_bn_train_bwd_acc(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                           const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                           float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                           int apply_act, void* stream);
 /* eval()-mode nn.BatchNorm2d (+ activation): the per-channel affine of the running statistics (SRGAN's generator at
  * validation time, model/srgan.py; the SRADSGAN discriminator is never put in eval()).  Inference only.   */
 int srhip_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
@@ -338,6 +344,10 @@ int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, co
                            const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
                            void* workspace, size_t workspace_bytes, long rows, int c, float slope, int apply_act,
                            void* stream);
+int srhip_bn_train_bwd_bwd_acc(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                               float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                               int apply_act, void* stream);   /* ABI 7: + acc_gamma[c] += g_gamma[c] unless NULL */
 
 /* ---- validation metrics (mfeNew_validate / validate, sradsgan.py:1314-1325; utils/utils.py:923-962):
  *      images quantised like ToPILImage (mul(255).byte(): truncate + wrap, no clamp), NHWC floats in.

@@ -92,6 +92,8 @@ SIGNATURES = {
     'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_bwd2_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_bwd_bwd': (_i, [_vp] * 11 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_train_bwd_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_metric_blocks': (_i, []),
     'srhip_quant_sse': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'srhip_ssim_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -1004,7 +1004,7 @@ class _UnpoolHW(Function):
     def forward(ctx, t, arg, shape):
         t = t.contiguous()
         n, c, h, w = shape
-        out = torch.empty(shape, device=t.device, dtype=torch.float32).contiguous(memory_format=CL)
+        out = torch.empty(shape, device=t.device, dtype=torch.float32, memory_format=CL)     # (not empty().contiguous(CL): that is a copy kernel)
         _hip.check(_hip.lib().srhip_cbam_unpool_hw(_p(t), _p(arg), _p(out), n, h * w, c, _stream()), 'cbam_unpool_hw')
         ctx.arg = arg
         return out
@@ -1055,7 +1055,7 @@ class _UnpoolC(Function):
     def forward(ctx, t, argc, shape):
         t = nhwc(t)
         n, c, h, w = shape
-        out = torch.empty(shape, device=t.device, dtype=torch.float32).contiguous(memory_format=CL)
+        out = torch.empty(shape, device=t.device, dtype=torch.float32, memory_format=CL)     # (not empty().contiguous(CL): that is a copy kernel)
         _hip.check(_hip.lib().srhip_cbam_unpool_c(_p(t), _p(argc), _p(out), n, h * w, c, _stream()), 'cbam_unpool_c')
         ctx.argc = argc
         return out
@@ -1303,7 +1303,9 @@ def _bn_reference_bwd(dy, x, y, gamma, eps, slope):
 
 class _BNTrainBwd(Function):
     @staticmethod
-    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope):
+    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope, acc_gamma=None, acc_beta=None):
+        # acc_gamma / acc_beta: the parameters' gradient slots (direct_param_grads mode): the kernel adds into them itself
+        # (srhip_bn_train_bwd_acc) instead of two add launches per BatchNorm backward
         # NB: save the tensors autograd handed us (not layout-converted copies), or the second-order
         # graph through x / dy would be cut
         dyc, xc, yc = nhwc(dy), nhwc(x), nhwc(y)
@@ -1313,9 +1315,9 @@ class _BNTrainBwd(Function):
         dx = torch.empty_like(xc, memory_format=CL)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(lib.srhip_bn_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
-        _hip.check(lib.srhip_bn_train_bwd(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
-                                          _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, rows, c,
-                                          float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
+        _hip.check(lib.srhip_bn_train_bwd_acc(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
+                                              _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws), ws.numel() * 4,
+                                              rows, c, float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
         ctx.eps, ctx.slope = eps, slope
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(dy, x, y, gamma, mean, invstd)
@@ -1325,7 +1327,7 @@ class _BNTrainBwd(Function):
     def backward(ctx, ddx, ddgamma, ddbeta):
         dy, x, y, gamma, mean, invstd = ctx.saved_tensors
         if ddx is None and ddgamma is None and ddbeta is None:
-            return (None,) * 8
+            return (None,) * 10
         if ddx is not None and ddgamma is None and ddbeta is None and not torch.is_grad_enabled():
             # the gradient-penalty case: one fused second-order pass (3 launches instead of ~40 ATen ops)
             uc, dyc, xc, yc = nhwc(ddx), nhwc(dy), nhwc(x), nhwc(y)
@@ -1335,22 +1337,21 @@ class _BNTrainBwd(Function):
             g_dy, g_x = torch.empty_like(xc, memory_format=CL), torch.empty_like(xc, memory_format=CL)
             g_gamma = torch.empty_like(gamma)
             ws = torch.empty(lib.srhip_bn_bwd2_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
-            _hip.check(lib.srhip_bn_train_bwd_bwd(_p(uc), _p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()),
-                                                  _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(ws),
-                                                  ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
-                                                  int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
-            slot = None if _skip_param_grads(gamma) else _grad_slot(gamma)
-            if slot is not None:                        # direct_param_grads(): straight into the arena, on this node's stream
-                slot.add_(g_gamma)
+            slot = None if _skip_param_grads(gamma) else _grad_slot(gamma)   # direct_param_grads(): straight into the arena, by the kernel
+            _hip.check(lib.srhip_bn_train_bwd_bwd_acc(_p(uc), _p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()),
+                                                      _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(slot), _p(ws),
+                                                      ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
+                                                      int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
+            if slot is not None:
                 g_gamma = None
-            return g_dy, g_x, None, g_gamma, None, None, None, None
+            return g_dy, g_x, None, g_gamma, None, None, None, None, None, None
         with torch.enable_grad():
             dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
             outs = _bn_reference_bwd(dy_, x_, y, g_, ctx.eps, ctx.slope)
             pairs = [(o, d) for o, d in zip(outs, (ddx, ddgamma, ddbeta)) if d is not None]
             gdy, gx, gg = torch.autograd.grad([o for o, _ in pairs], [dy_, x_, g_], [d for _, d in pairs],
                                               allow_unused=True)
-        return gdy, gx, None, gg, None, None, None, None
+        return gdy, gx, None, gg, None, None, None, None, None, None
 
 
 class _BNTrainFwd(Function):
@@ -1375,16 +1376,15 @@ class _BNTrainFwd(Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mean, invstd, beta = ctx.saved_tensors
-        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope)
         if not torch.is_grad_enabled() and not _skip_param_grads(gamma, beta):
             # direct_param_grads(): add into the arena slots here, on the stream this node runs on, instead of handing the
             # gradients to autograd -- its AccumulateGrad nodes run on the stream the parameter was FIRST used on in this
             # iteration (the main stream, D(gen_hr)), which would make the main stream wait for the D stream's backward
             gg, gb = _grad_slot(gamma), _grad_slot(beta)
             if gg is not None and gb is not None:
-                gg.add_(dgamma)
-                gb.add_(dbeta)
+                dx, _, _ = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, gg, gb)
                 return dx, None, None, None, None, None, None, None
+        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
