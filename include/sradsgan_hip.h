@@ -177,6 +177,10 @@ int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_b
 /* ---- elementwise / permutation pieces of the same call sites --------------------------------- */
 /* dx = dy * (y > 0 ? 1 : slope): backward of the in-place LeakyReLU (:242,:479) from its OUTPUT  */
 int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream);
+/* ABI 7: out = ((srcs[0] + srcs[1]) + srcs[2]) + ... (n = 2..16 dense tensors of `count` floats, count % 4 == 0, 16-byte aligned):
+ * the stratified dense-sampling bus of GeneratorResNet.forward (sradsgan.py:455-460: `bus = bus + out` after every residual
+ * group) in one pass, same summation order as the chained torch adds it replaces.                                            */
+int srhip_sum_n(const float* const* srcs, int n, float* out, long count, void* stream);
 /* nn.MaxPool2d(2,2) of vgg19.features[4] / [9] (sradsgan.py:92-95) on NHWC, even H and W, C % 4 == 0.
  * bwd recomputes the argmax from x (first maximum in window scan order, like ATen); relu_input != 0
  * also applies the backward of the ReLU that produced x (dx = 0 where the window maximum is 0).   */

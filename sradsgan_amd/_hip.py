@@ -92,6 +92,7 @@ SIGNATURES = {
     'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_bwd2_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_bwd_bwd': (_i, [_vp] * 11 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_sum_n': (_i, [_vp, _i, _vp, _l, _vp]),
     'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_metric_blocks': (_i, []),

@@ -243,10 +243,11 @@ class GeneratorResNet(nn.Module):
     def forward(self, x):
         x = ops.nhwc(x)
         out = self.conv1[0](x, act_slope=0.01)
-        bus = self.MSB(x) + out
+        terms = [self.MSB(x), out]
         for group in self.res_groups:
             out = group(out)
-            bus = bus + out                  # stratified dense sampling bus, sradsgan.py:455-460
+            terms.append(out)                # stratified dense sampling bus, sradsgan.py:455-460: bus = bus + out per group,
+        bus = ops.sum_tensors(terms)         # summed once, in the same order (srhip_sum_n)
         return self.conv3[0](self.GAB_UP(bus))
 
 

@@ -32,8 +32,7 @@ class _State:
     capturing = False               # a stream capture is being recorded (TrainStep._capture): side-stream forks go through torch events
     wgrad_group = 1                 # weight gradients of one shape launched together (srhip_conv2d_wgrad_multi); 1 = off
     pending = None                  # shape key -> [(x, dy, gw, gb, stride, pad)] waiting for partners (direct_param_grads mode)
-    held = None                     # [[event | None, [tensors]]]: operands of side-stream kernels, see _hold_for_side
-    hold_n = 0
+    held = None                     # gradients kept referenced until the backward ends, see _passed_through
 
 
 _state = _State()
@@ -82,7 +81,7 @@ def direct_param_grads(side_stream=None, group=1):
     and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
     prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held)
     _state.direct_grads, _state.wgrad_stream = True, side_stream
-    _state.wgrad_group, _state.pending, _state.held = (group if side_stream is not None else 1), {}, [[None, []]]
+    _state.wgrad_group, _state.pending, _state.held = (group if side_stream is not None else 1), {}, []
     try:
         yield
         flush_pending_wgrads()
@@ -90,41 +89,33 @@ def direct_param_grads(side_stream=None, group=1):
         _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held = prev
 
 
-_HOLD = os.environ.get('SRHIP_HOLD', '1') == '1'      # 0: test knob, reproduces the pass-through race (tests/test_model_gpu.py)
+_HOLD = int(os.environ.get('SRHIP_HOLD', '1'))     # 1: passed-through gradients (default); 2: every side-stream operand; 0: off (test knob)
 
 
 def _hold_for_side(side, *tensors):
-    """Keeps `tensors` (operands of a kernel just launched on the side stream) referenced until the side stream has got past
-    that kernel.  record_stream() protects their MEMORY; this protects their CONTENTS: autograd's input buffer adds later
-    contributions IN PLACE into a gradient it holds the only reference to (torch/csrc/autograd/input_buffer.cpp,
-    use_count() == 1), on the main stream, which the side stream may trail by a millisecond.  A gradient a backward hands
-    back unchanged (the skip of the attention tail, the residual of a conv, the second consumer of a torch add) while its
-    weight-gradient kernel still waits on the side stream was modified under that kernel: ResGroup tail conv gradients
-    off by 10-30 % whenever the side stream lagged (tests/test_model_gpu.py, first-step test with two pool streams).
-    With a second reference alive the engine allocates the sum instead.  Every 8th launch closes the open group with an
-    event on the side stream; groups whose event has completed are dropped, so the extra lifetime is the lag itself."""
-    h = _state.held
-    if h is None or not _HOLD:
-        return
-    h[-1][1].extend(t for t in tensors if t is not None)
-    _state.hold_n += 1
-    if _state.hold_n % 8 or _state.capturing:
-        return
-    ev = torch.cuda.Event()
-    ev.record(side)
-    h[-1][0] = ev
-    while len(h) and h[0][0] is not None and h[0][0].query():
-        h.pop(0)
-    h.append([None, []])
+    """SRHIP_HOLD=2 only: keeps EVERY operand gradient of a side-stream launch referenced until the backward ends (see
+    _passed_through for why a reference matters).  The default holds only the gradients that are known to be aliased; holding
+    all of them costs 1.5 % of the step (the allocator hands out cold blocks instead of the ones just freed:
+    profiles/r04_step_ab_small_changes.txt) and protects against graph shapes the model does not have -- a gradient that one
+    producer hands to several consumers (torch's AddBackward, ops._SumN) is shared until the last of them has run, and the
+    trunk's bus gradient is held by the head convs' buffers until the end of the backward."""
+    if _HOLD >= 2 and _state.held is not None:
+        _state.held.extend(t for t in tensors if t is not None)
 
 
 def _passed_through(g):
-    """Marks an incoming gradient that a backward returns UNCHANGED as the gradient of one of its inputs (see
-    _hold_for_side: the engine must not add into it in place while a side-stream kernel reads it).  The kernels' own launch
-    sites hold their operands already; this covers the window in which a grouped weight gradient has been flushed by a
-    partner before this backward returns."""
-    if _state.wgrad_stream is not None and _state.held is not None and g is not None and _HOLD:
-        _state.held[-1][1].append(g)
+    """Call on an incoming gradient that a backward returns UNCHANGED as the gradient of one of its inputs while a weight-gradient
+    kernel on the side stream reads it.  record_stream() protects the tensor's MEMORY; this protects its CONTENTS: autograd's
+    input buffer adds later contributions IN PLACE into a gradient it holds the only reference to
+    (torch/csrc/autograd/input_buffer.cpp, use_count() == 1), on the main stream, which the side stream may trail by a
+    millisecond.  The attention tail hands `g` back as the gradient of `skip`, a conv with a fused residual hands it back as the
+    residual's: when the ResGroup's first RAB delivered its data gradient 1 ms later the engine ran `g += dx` under the tail
+    conv's weight-gradient kernel -- ResGroup tail conv gradients off by 10-30 % whenever the side stream lagged
+    (tests/test_model_gpu.py: the first-step test after two pool streams, and the lagging-side-stream test).  With a second
+    reference alive until the backward ends the engine allocates the sum instead, which is what it does for every gradient
+    that is not aliased (12 + a few tensors of 24 MB per step)."""
+    if _HOLD and _state.wgrad_stream is not None and _state.held is not None and g is not None:
+        _state.held.append(g)
     return g
 
 
@@ -760,6 +751,39 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=None, residual=N
     """nn.Conv2d forward with the elementwise tail of its call site fused (bias, LeakyReLU/ReLU,
     residual add).  x: logical NCHW; returns logical NCHW in NHWC memory."""
     return _ConvFwd.apply(x, weight, bias, residual, stride, padding, act_slope)
+
+
+_BUS_SUM = os.environ.get('SRHIP_BUS_SUM', '1') == '1'      # A/B knob: 0 = chained torch adds
+
+
+class _SumN(Function):
+    """((t0 + t1) + t2) + ... in one pass (srhip_sum_n); every term gets the incoming gradient, as with chained adds."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        _require_gpu(ts[0], 'sum_n')
+        ts = [nhwc(t) for t in ts]
+        out = torch.empty_like(ts[0], memory_format=CL)
+        tab = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _hip.check(_hip.lib().srhip_sum_n(tab, len(ts), _p(out), out.numel(), _stream()), 'sum_n')
+        ctx.n = len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_tensors(ts):
+    """Sum of 2..16 same-shape NCHW tensors in the order given (the generator's bus); falls back to chained adds otherwise."""
+    ts = list(ts)
+    if (_BUS_SUM and 2 <= len(ts) <= 16 and ts[0].is_cuda and ts[0].dim() == 4 and ts[0].numel() % 4 == 0
+            and all(t.shape == ts[0].shape and t.dtype == torch.float32 for t in ts)):
+        return _SumN.apply(*ts)
+    out = ts[0]
+    for t in ts[1:]:
+        out = out + t
+    return out
 
 
 # --------------------------------------------------------------------------------------------- #

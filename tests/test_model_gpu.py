@@ -535,3 +535,21 @@ def test_weight_gradient_on_a_lagging_side_stream_reads_the_gradient_it_was_laun
     got = run(torch.cuda.Stream())
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), (op, i, float((a - b).abs().max()), float(a.abs().max()))
+
+
+@pytest.mark.parametrize('n_terms', [2, 3, 14, 16, 17])
+def test_bus_sum_is_bit_identical_to_chained_adds(n_terms):
+    """srhip_sum_n (the generator's stratified bus, sradsgan.py:455-460, as one pass) adds its terms in the order of the chained
+    `bus = bus + out` it replaces: same bits, and every term receives the incoming gradient.  17 terms take the fallback."""
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(n_terms)
+    ts = [torch.randn(2, 64, 13, 17, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for _ in range(n_terms)]
+    ref = ts[0]
+    for t in ts[1:]:
+        ref = ref + t
+    got = ops.sum_tensors(ts)
+    assert torch.equal(ref, got)
+    dy = torch.randn(2, 64, 13, 17, generator=g).to(DEV)
+    got.backward(dy)
+    assert all(torch.equal(t.grad, dy) for t in ts)
