@@ -266,12 +266,12 @@ __global__ void tail_bwd_da_kernel(const float* __restrict__ dz, const float* __
 }
 
 // ---- B2a: dpooled[pix][ch] = sum_{kh,kw} w7[ch][kh][kw] * da[(y-kh+3, x-kw+3)] --------------------- //
-__global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const float* __restrict__ w7,
-                                        float2* __restrict__ dpooled, int h, int w, long npix) {
+__device__ __forceinline__ void slam_conv7_dgrad_block(const float* __restrict__ da, const float* __restrict__ w7,
+                                                       float2* __restrict__ dpooled, int h, int w, long npix, int bid) {
   __shared__ float sw[98];
   if (threadIdx.x < 98) sw[threadIdx.x] = w7[threadIdx.x];
   __syncthreads();
-  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long pix = (long)bid * blockDim.x + threadIdx.x;
   if (pix >= npix) return;
   const int hw = h * w;
   const long b = pix / hw;
@@ -297,6 +297,10 @@ __global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const floa
   }
   dpooled[pix] = make_float2(a0, a1);
 }
+__global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const float* __restrict__ w7,
+                                        float2* __restrict__ dpooled, int h, int w, long npix) {
+  slam_conv7_dgrad_block(da, w7, dpooled, h, w, npix, blockIdx.x);
+}
 
 // ---- B2b: dw7[ch][kh][kw] = sum_pix da[pix] * pooled[(y+kh-3, x+kw-3)][ch] ---------------------------- //
 // Every thread takes one pixel and all 98 taps (register accumulators), waves reduce with shuffles,
@@ -306,11 +310,10 @@ __global__ void slam_conv7_dgrad_kernel(const float* __restrict__ da, const floa
 // no cross-lane reduction (the first version kept 98 accumulators per pixel-thread and spent its time in 98
 // wave reductions: 53 us for 9 MFLOP).  part[tap][block] feeds slam_conv7_wgrad_reduce_kernel.
 constexpr int W7_ROWS = 8;
-__global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __restrict__ da,
-                                                                const float2* __restrict__ pooled,
-                                                                float* __restrict__ part, int h, int w, int strips) {
+__device__ __forceinline__ void slam_conv7_wgrad_block(const float* __restrict__ da, const float2* __restrict__ pooled,
+                                                       float* __restrict__ part, int h, int w, int strips, int bid, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float w7lds[];
-  const int b = blockIdx.x / strips, sidx = blockIdx.x - b * strips;
+  const int b = bid / strips, sidx = bid - b * strips;
   const int y0 = sidx * W7_ROWS;
   const int rows = min(W7_ROWS, h - y0);
   const int wp = w + 6;
@@ -336,8 +339,23 @@ __global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __re
       for (int x = 0; x < w; ++x) acc += grow[x] * prow[2 * x];
     }
     acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) part[(size_t)t * gridDim.x + blockIdx.x] = acc;   // tap-major partials: the reduce reads them contiguously
+    if (half == 0) part[(size_t)t * nblk + bid] = acc;   // tap-major partials: the reduce reads them contiguously
   }
+}
+__global__ __launch_bounds__(256) void slam_conv7_wgrad_kernel(const float* __restrict__ da,
+                                                                const float2* __restrict__ pooled,
+                                                                float* __restrict__ part, int h, int w, int strips) {
+  slam_conv7_wgrad_block(da, pooled, part, h, w, strips, blockIdx.x, gridDim.x);
+}
+// Round 4: both halves of the 7x7 conv's backward behind ONE launch (they only share their input `da`): blocks [0, nd) do the data
+// gradient, blocks [nd, nd + nw) the weight-gradient strips.  Inside the step every launch of the tail's serial chain waits for
+// block slots the weight-gradient stream holds (13-29 us per launch in the step for kernels that take 4-10 us alone).
+__global__ __launch_bounds__(256) void slam_conv7_bwd_kernel(const float* __restrict__ da, const float* __restrict__ w7,
+                                                              const float2* __restrict__ pooled, float2* __restrict__ dpooled,
+                                                              float* __restrict__ part, int h, int w, long npix, int strips,
+                                                              int nd, int nw) {
+  if ((int)blockIdx.x < nd) slam_conv7_dgrad_block(da, w7, dpooled, h, w, npix, blockIdx.x);
+  else slam_conv7_wgrad_block(da, pooled, part, h, w, strips, (int)blockIdx.x - nd, nw);
 }
 __global__ void slam_conv7_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw7, int nblk,
                                                int accumulate) {
@@ -917,8 +935,9 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
   const size_t w7lds = ((size_t)W7_ROWS * w + 2 * (size_t)(W7_ROWS + 6) * (w + 6)) * sizeof(float);
   SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd: image too wide for the 7x7 weight-gradient strip");
   hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
-  hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
-  hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), w7lds, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, strips);
+  const int nd7 = (int)cdiv(npix, 256);
+  hipLaunchKernelGGL(slam_conv7_bwd_kernel, dim3(nd7 + w7blk), dim3(256), w7lds, st, da, w7, reinterpret_cast<const float2*>(pooled), dpooled,
+                     w7part, h, w, npix, strips, nd7, w7blk);
   hipLaunchKernelGGL(tail_bwd_main_kernel<true>, dim3(TAIL_BLK + 1, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw,
                      w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
