@@ -936,8 +936,13 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
   SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd: image too wide for the 7x7 weight-gradient strip");
   hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
   const int nd7 = (int)cdiv(npix, 256);
-  hipLaunchKernelGGL(slam_conv7_bwd_kernel, dim3(nd7 + w7blk), dim3(256), w7lds, st, da, w7, reinterpret_cast<const float2*>(pooled), dpooled,
-                     w7part, h, w, npix, strips, nd7, w7blk);
+  if (g_tail_dbg & 16) {                              // srhip_debug_set(7, 16): the two launches of rounds 2-3 (A/B)
+    hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(nd7), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
+    hipLaunchKernelGGL(slam_conv7_wgrad_kernel, dim3(w7blk), dim3(256), w7lds, st, da, reinterpret_cast<const float2*>(pooled), w7part, h, w, strips);
+  } else {
+    hipLaunchKernelGGL(slam_conv7_bwd_kernel, dim3(nd7 + w7blk), dim3(256), w7lds, st, da, w7, reinterpret_cast<const float2*>(pooled), dpooled,
+                       w7part, h, w, npix, strips, nd7, w7blk);
+  }
   hipLaunchKernelGGL(tail_bwd_main_kernel<true>, dim3(TAIL_BLK + 1, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw,
                      w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
