@@ -188,6 +188,41 @@ def test_batch_norm_lrelu_fwd_bwd_double_bwd(shape):
     assert int(got[7]) == int(ref[7]) == 1
 
 
+@pytest.mark.parametrize('shape', [(4, 64, 9, 7), (2, 256, 14, 14)])
+def test_batch_norm_backward_accumulates_parameter_gradients_itself(shape):
+    """srhip_bn_train_bwd_acc / srhip_bn_train_bwd_bwd_acc (ABI 7): in direct_param_grads() mode the kernels add dgamma / dbeta
+    (and the second-order dgamma of the gradient penalty) into the parameters' existing .grad buffers, for the first-order pass
+    and for the penalty's double backward; compared with autograd's own accumulation of the same graph."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c * 3 + h)
+    x = (torch.randn(n, c, h, w, generator=g) * 0.7 + 0.3).to(dev)
+    dy = torch.randn(n, c, h, w, generator=g).to(dev)
+    gamma0, beta0 = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+    seed_g, seed_b = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)
+
+    def run(direct):
+        bn = torch.nn.BatchNorm2d(c).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma0), bn.bias.copy_(beta0)
+        bn.weight.grad, bn.bias.grad = seed_g.clone(), seed_b.clone()
+        xx = x.clone().requires_grad_()
+        y = ops.batch_norm_act(xx, bn, 0.2)
+        (gx,) = torch.autograd.grad(y, xx, dy, create_graph=True)               # first order, differentiable (the penalty's inner pass)
+        pen = ((gx.norm(2, 1) - 1) ** 2).mean() + (y * dy).mean()
+        if direct:
+            with ops.direct_param_grads(None):
+                pen.backward()                                                  # second-order pass + a plain first-order pass
+        else:
+            pen.backward()
+        return bn.weight.grad.clone(), bn.bias.grad.clone(), xx.grad.clone()
+
+    ref, got = run(False), run(True)
+    for name, a, b in zip(('dgamma', 'dbeta', 'dx'), got, ref):      # (autograd sums the two contributions before adding them to .grad: last-bit differences)
+        assert _rel(a, b) < 1e-6, (name, float((a - b).abs().max()))
+
+
 @pytest.fixture(params=['fp32', 'bf16x3'])
 def force_dma(request):
     """The LDS-DMA conv kernels are normally chosen only for >= 512 tiles; force them for small test shapes,
