@@ -57,6 +57,7 @@ extern int g_fast_cfg;
 extern int g_wgrad_cfg;
 extern int g_rowtap_addr;
 extern int g_rowtap_pipe;
+extern int g_patch_ks;
 extern int g_fast_dynlds;
 extern int g_fast_ablate;
 extern int g_conv_math;
@@ -169,6 +170,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 9) {
     g_rowtap_pipe = value;
+    return SRHIP_OK;
+  }
+  if (key == 10) {
+    g_patch_ks = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -919,6 +919,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 }
 
 // ================================================================================================ //
+// K-split form of the one-tile patch kernel for 64 destination channels (round 4): conv2's fprop (256 -> 64) and conv1's dgrad.
+// With BN = 64 the 2 x 2 wave grid above gives a wave 64 pixels x 32 channels: 6 MFMAs for 6 ds_read_b128 per tap, against 12 for
+// 8 in the 128-wide tile -- the fragment reads of three blocks per CU then take as long as their MFMAs (12 waves x 6 x 8 clk of
+// LDS against 3 waves x 6 x 32 clk per SIMD), which is why these convs sat at 0.40 while the wide ones reached 0.44.  Here the
+// second wave column splits K instead of N: wave (wm, wk) owns 64 pixels x ALL 64 channels and every second tap of the
+// (chunk, tap) sequence -- T = 2 s + wk at step s --, so a step is one barrier, 8 fragment reads and 12 MFMAs per wave, like the
+// wide tile.  The tap sequence of a PAIR of 16-channel chunks (18 taps, 9 steps) is the unit of the compile-time schedule: the
+// patch of the pair's second chunk arrives during steps 0-1, the next pair's first patch during steps 5-6, weight tiles run
+// four taps ahead in a six-slot ring (T mod 6: the pattern repeats per pair).  At the end the two K halves are added through LDS
+// (each wave hands its partner the 32 channels the partner stores), then the usual epilogue.  The sum is grouped differently
+// from fast_conv_dma_kernel's (two partial sums per output), so results agree with it to rounding, not bit for bit.
+// Requires an even number of chunks (C % 32 == 0).
+// ================================================================================================ //
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_ks_kernel(
+    const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias, const float* __restrict__ residual,
+    const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g, PatchGeom pg, int nblk_m, int nblk_n) {
+  constexpr int BN = 64, NW = 4, BK = 16, TM = 2, TN = 2, MAXP = 3, NST = 6;
+  constexpr int PATCH_B = 12 * 1024, BSTAGE_B = BN * 64;
+  constexpr int LDS_B = 2 * PATCH_B + NST * BSTAGE_B;          // 48 KB (the K exchange takes 32 KB of it, the epilogue 16 KB)
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
+  __shared__ int pix_tab[128];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
+  const int tile_n = tile % nblk_n, pid = tile / nblk_n;
+  const int n0 = tile_n * BN;
+  const int tpi = pg.tiles_h * pg.tiles_w;
+  const int img = pid / tpi;
+  const int prem = pid - img * tpi;
+  const int ty = prem / pg.tiles_w, tx = prem - ty * pg.tiles_w;
+  const int oh0 = ty * pg.PH, ow0 = tx * pg.PW;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  if (tid < 128) {
+    int pr_, pc_;
+    patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
+    pix_tab[tid] = (pr_ << 16) | pc_;
+  }
+  __syncthreads();
+
+  const int swz = (lane >> 4) & 3;
+  const int aq = (lane & 3) ^ swz;
+  unsigned aoffb[MAXP];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int row = (k * NW + wave) * 16 + (lane >> 2);
+    aoffb[k] = F_OOB;
+    if (row < pg.PR) {
+      const int pi = row / pg.PWP, pj = row - pi * pg.PWP;
+      const int sh = oh0 + pg.lo_h + pi, sw = ow0 + pg.lo_w + pj;
+      if (sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws) aoffb[k] = (unsigned)(((img * g.Hs + sh) * g.Ws + sw) * g.lds + aq * 4) * 4u;
+    }
+  }
+  unsigned boffb;
+  {
+    const int n = n0 + wave * 16 + (lane >> 2);
+    boffb = n < g.K ? (unsigned)(n * g.ldw + aq * 4) * 4u : F_OOB;
+  }
+  const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+  const unsigned b_dst = __builtin_amdgcn_readfirstlane(lds_base + 2 * PATCH_B + wave * 1024);
+  const int CC = g.C / BK;
+  int wtap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wtap[t] = ((g.kh0 + (t / 3) * g.khs) * g.KW + (g.kw0 + (t % 3) * g.kws)) * g.C;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
+  auto issue_a = [&](int buf, int k, int cc) {
+    lds_dma16_buf(aoffb[k] + (unsigned)(cc * BK * 4), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
+  };
+  auto issue_b = [&](int stage, int tap, int cc) {
+    lds_dma16_buf(boffb + (unsigned)((wtap[tap] + cc * BK) * 4), rs_b, b_dst + stage * BSTAGE_B);
+  };
+  auto convert_piece = [&](int buf, int k) {          // as in conv_patch_kernel (split-bf16)
+    float4* slot = reinterpret_cast<float4*>(lds + buf * PATCH_B + (k * NW + wave) * 1024 + lane * 16);
+    const float4 own = *slot;
+    float4 oth;
+    oth.x = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.x), 0xB1, 0xF, 0xF, true));
+    oth.y = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.y), 0xB1, 0xF, 0xF, true));
+    oth.z = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.z), 0xB1, 0xF, 0xF, true));
+    oth.w = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, own.w), 0xB1, 0xF, 0xF, true));
+    const bool odd = aq & 1;
+    bf16x8_t hi, lo;
+    split_bf16x8(odd ? oth : own, odd ? own : oth, hi, lo);
+    *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
+  };
+
+  // ---- fragment addressing by STEP: this wave's tap at step s of a chunk pair is T = 2 s + wk (chunk T / 9, tap T % 9) ----
+  const int wm = wave >> 1, wk = wave & 1;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  int aoffS[9][TM];                                 // byte offset of the hi quad, patch buffer (= chunk parity) included
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int r = wm * 64 + t * 32 + l31;
+    const int pt = pix_tab[r];
+    const int orow = pt >> 16, ocol = pt & 0xffff;
+    const int arow = orow < pg.PH ? orow * pg.PWP + ocol : 0;
+#pragma unroll
+    for (int sidx = 0; sidx < 9; ++sidx) {
+      const int T = 2 * sidx + wk;
+      const int par = T >= 9 ? 1 : 0, tap = T - 9 * par;
+      const int th = tap / 3, tw = tap - 3 * th;
+      const int a_th = (g.dh0 + th * g.dhs) - pg.lo_h, a_tw = (g.dw0 + tw * g.dws) - pg.lo_w;
+      const int pr = arow + a_th * pg.PWP + a_tw;
+      aoffS[sidx][t] = par * PATCH_B + pr * 64 + (((2 * khalf) ^ ((pr >> 2) & 3)) << 4);
+    }
+  }
+  int boffk[TN];                                    // ring base + this K group's slot of a step's pair + the fragment row
+#pragma unroll
+  for (int u = 0; u < TN; ++u) {
+    const int row = u * 32 + l31;
+    boffk[u] = 2 * PATCH_B + wk * BSTAGE_B + row * 64 + (((2 * khalf) ^ ((row >> 2) & 3)) << 4);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t)
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+  // One step of a chunk pair (compile-time step index and "last pair" flag: every DMA, conversion, ring slot and vmcnt count is
+  // an immediate).  DMAs per wave and step: s0 A A B B | s1 A B B | s2-s4 B B | s5 A A B B | s6 A B B | s7, s8 B B; the last pair
+  // drops the next pair's patch (s5, s6) and weight tiles (s7, s8).  At step s the weight tiles of taps 2 s and 2 s + 1 (the last
+  // two DMAs of step s - 2) must have landed: everything issued at step s - 1 may stay in flight.
+  auto do_step = [&](auto sc, auto lastc, int cc0) {
+    constexpr int S = decltype(sc)::value;
+    constexpr bool LAST = decltype(lastc)::value != 0;
+    constexpr int NEWER = S == 0 ? 2 : S == 1 ? 4 : S == 2 ? 3 : (S >= 3 && S <= 5) ? 2 : S == 6 ? (LAST ? 2 : 4) : S == 7 ? (LAST ? 2 : 3) : (LAST ? 0 : 2);
+    wait_vmcnt<NEWER>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (S == 0) {
+      issue_a(1, 0, cc0 + 1);
+      issue_a(1, 1, cc0 + 1);
+    }
+    if (S == 1) issue_a(1, 2, cc0 + 1);
+    if (!LAST && S == 5) {
+      issue_a(0, 0, cc0 + 2);
+      issue_a(0, 1, cc0 + 2);
+    }
+    if (!LAST && S == 6) issue_a(0, 2, cc0 + 2);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      constexpr int T0 = 2 * S + 4;
+      const int T = T0 + d;
+      if (T < 18) issue_b(T % NST, T % 9, cc0 + T / 9);
+      else if (!LAST) issue_b(T % NST, (T - 18) % 9, cc0 + 2 + (T - 18) / 9);
+    }
+    if (S == 2) {
+      convert_piece(1, 0);
+      convert_piece(1, 1);
+    }
+    if (S == 3) convert_piece(1, 2);
+    if (!LAST && S == 7) {
+      convert_piece(0, 0);
+      convert_piece(0, 1);
+    }
+    if (!LAST && S == 8) convert_piece(0, 2);
+    const char* sb = lds + ((2 * S) % NST) * BSTAGE_B;
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      ah[t] = *reinterpret_cast<const bf16x8_t*>(lds + aoffS[S][t]);
+      al[t] = *reinterpret_cast<const bf16x8_t*>(lds + (aoffS[S][t] ^ 16));
+    }
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+      bh[u] = *reinterpret_cast<const bf16x8_t*>(sb + boffk[u]);
+      bl[u] = *reinterpret_cast<const bf16x8_t*>(sb + (boffk[u] ^ 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * TM * TN; ++i) {         // same product order as the other split-bf16 kernels: al*bh, ah*bl, ah*bh
+      const int grp = i / (TM * TN), t = (i % (TM * TN)) / TN, u = i % TN;
+      acc[t][u] = mma16<0>(grp == 0 ? al[t] : ah[t], grp == 1 ? bl[u] : bh[u], acc[t][u]);
+    }
+  };
+  auto do_pair = [&](auto lastc, int cc0) {
+    do_step(IC<0>(), lastc, cc0);
+    do_step(IC<1>(), lastc, cc0);
+    do_step(IC<2>(), lastc, cc0);
+    do_step(IC<3>(), lastc, cc0);
+    do_step(IC<4>(), lastc, cc0);
+    do_step(IC<5>(), lastc, cc0);
+    do_step(IC<6>(), lastc, cc0);
+    do_step(IC<7>(), lastc, cc0);
+    do_step(IC<8>(), lastc, cc0);
+  };
+
+  // prologue: the patch of chunk 0, the weight tiles of taps 0..3; the patch is converted once it is in (the tiles stay in flight)
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
+  issue_b(0, 0, 0);
+  issue_b(1, 1, 0);
+  issue_b(2, 2, 0);
+  issue_b(3, 3, 0);
+  wait_vmcnt<4>();
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+  for (int cc0 = 0; cc0 + 2 < CC; cc0 += 2) do_pair(IC<0>(), cc0);
+  do_pair(IC<1>(), CC - 2);
+
+  // ---- add the two K halves: a wave hands its partner (same pixels, other K group) the 32 channels the partner stores ----
+  __syncthreads();
+  {
+    float* xl = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xl[((wave * TM + t) * 16 + r) * 64 + lane] = wk ? acc[t][0][r] : acc[t][1][r];
+    __syncthreads();
+    const int pw = wave ^ 1;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float o = xl[((pw * TM + t) * 16 + r) * 64 + lane];
+        acc[t][0][r] = (wk ? acc[t][1][r] : acc[t][0][r]) + o;
+      }
+    __syncthreads();
+  }
+
+  // ---- epilogue: as conv_patch_kernel<64> with wn = wk (wave = 64 pixels x 32 channels) ----
+  const int flags = EPI >= 0 ? EPI : g.flags;
+  constexpr int WTN = 32;
+  float* wl = reinterpret_cast<float*>(lds) + wave * (32 * WTN);
+  constexpr int QPRW = WTN / 4;
+  constexpr int NRD = 32 * QPRW / 64;
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + l31] = acc[t][0][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float4 vq[NRD];
+    EpiOps eo[NRD];
+    unsigned dpx[NRD];
+    int nq[NRD];
+    bool okq[NRD];
+#pragma unroll
+    for (int j = 0; j < NRD; ++j) {
+      const int idx = j * 64 + lane;
+      const int row = idx / QPRW, cq = idx - row * QPRW;
+      vq[j] = *reinterpret_cast<const float4*>(wl + row * WTN + cq * 4);
+      const int r = wm * 64 + t * 32 + row;
+      const int pt = pix_tab[r];
+      const int orow = pt >> 16, ocol = pt & 0xffff;
+      const int oh = oh0 + orow, ow = ow0 + ocol;
+      const int n = n0 + wk * WTN + cq * 4;
+      okq[j] = !(orow >= pg.PH || oh >= g.OH || ow >= g.OW || n >= g.K);
+      dpx[j] = okq[j] ? (unsigned)((img * g.Hd + oh) * g.Wd + ow) : 0u;
+      nq[j] = okq[j] ? n : 0;
+      eo[j] = epi_fetch(dpx[j], nq[j], flags, g, bias, residual, nullptr, actmask, dst, false);
+    }
+#pragma unroll
+    for (int j = 0; j < NRD; ++j)
+      if (okq[j]) epi_finish(vq[j], eo[j], dpx[j], nq[j], flags, g, dst, false);
+    if (t + 1 < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// ================================================================================================ //
 // Stride-1 3x3 convolutions with <= 4 destination channels (generator tail conv 64 -> 3, discriminator head dgrad
 // 64 -> 3) at full image size.  A 32-wide MFMA tile wastes 10x the arithmetic there and the op is HBM-bound
 // (one read of the source); this kernel does the 1728 multiply-adds per pixel on the VALU in exact fp32:
@@ -2226,6 +2488,7 @@ __global__ __launch_bounds__(256) void dot_conv_kernel(const float* __restrict__
 }
 
 // experiment knob (srhip_debug_set(0, cfg)): 0 = heuristic below
+int g_patch_ks = 1;    // srhip_debug_set(10, v): 0 = conv_patch_kernel<64> instead of conv_patch_ks_kernel (bit-identical to the DMA kernel; A/B and pinned tests)
 int g_fast_cfg = 0;
 
 // Patch shape for conv_patch_kernel: PH x PW output pixels per block (<= 128), halo patch <= 192 rows = 12 DMA pieces; picks the
@@ -2379,6 +2642,19 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     SRHIP_LP(BN_, -1);                                                  \
   } while (0)
         if (wide) SRHIP_LPE(128);
+        if (g_patch_ks && g.C % 32 == 0 && g.C >= 32) {    // K-split form of the 64-wide tile (srhip_debug_set(10, 0): the 2 x 2 wave grid of rounds 1-3)
+#define SRHIP_LK(EPI_)                                                                                              \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((conv_patch_ks_kernel<EPI_>), dim3(nbm * nbn), dim3(256), 0, st, src, wsplit, bias, residual, \
+                       actmask, dst, g, pg, nbm, nbn);                                                             \
+    return check_launch("conv_patch_ks");                                                                           \
+  } while (0)
+          if (eflags == 0) SRHIP_LK(0);
+          if (eflags == SRHIP_EPI_BIAS) SRHIP_LK(1);
+          if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_LK(4);
+          SRHIP_LK(-1);
+#undef SRHIP_LK
+        }
         SRHIP_LPE(64);
 #undef SRHIP_LPE
 #undef SRHIP_LP

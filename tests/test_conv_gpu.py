@@ -312,10 +312,12 @@ def test_patch_conv_kernel_bit_identical_to_dma_kernel(case):
     with ops.conv_math('bf16x3'):
         for cfg in (-1, -2):                     # -1: force the LDS-DMA kernel, -2: force the patch kernel
             lib.srhip_debug_set(0, cfg)
+            lib.srhip_debug_set(10, 0)           # the 64-wide tile's K-split form sums in another order: see test_k_split_patch_kernel_...
             try:
                 out[cfg] = (ops.conv2d_fwd_raw(x, wt, b, 1, 1, 0.2), ops.conv2d_dgrad_raw(dy, wt, tuple(x.shape), 1, 1, r, x, 0.2))
             finally:
                 lib.srhip_debug_set(0, 0)
+                lib.srhip_debug_set(10, 1)
     assert torch.equal(out[-1][0], out[-2][0])
     assert torch.equal(out[-1][1], out[-2][1])
     ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=1), 0.2)
@@ -359,6 +361,62 @@ def test_persistent_patch_kernel_bit_identical_to_dma_kernel(case, grid):
         finally:
             lib.srhip_debug_set(0, 0)
             lib.srhip_debug_set(5, 0)
+
+
+@pytest.mark.parametrize('case', [(1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (1, 64, 108, 108, 64), (3, 32, 23, 37, 64), (2, 64, 3, 70, 64),
+                                  (2, 256, 27, 27, 96)])
+def test_k_split_patch_kernel_against_dma_kernel_and_fp64(case):
+    """conv_patch_ks_kernel (round 4: the 64-wide one-tile patch kernel with its second wave column splitting K instead of N,
+    chunk pairs as the unit of the schedule, the two K halves added through LDS) against fast_conv_dma_kernel<bf16x3> -- same
+    products, sums grouped differently, so equal to a few ulps of the accumulated magnitude, not bit for bit -- and against an
+    fp64 convolution: fprop with bias, with bias + LeakyReLU (run-time epilogue flags), plain; dgrad with residual, with
+    activation mask + residual, plain; 2, 4, 8 and 16 chunks, ragged tiles, 96 destination channels (a half-empty second
+    N tile).  srhip_debug_set(0, -2) sends small problems to the patch family, (5, -1) keeps the persistent walk out."""
+    import torch.nn.functional as F
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev))
+    b = torch.randn(cout, generator=g)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    # data gradient of a conv whose INPUT has `cout` channels: destination = cout channels, source = cin channels
+    wd = torch.nn.Parameter((torch.randn(cin, cout, 3, 3, generator=g) * 0.05).to(dev))
+    dy = torch.randn(n, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    am = torch.randn(n, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    dshape = (n, cout, h, w)
+
+    def run():
+        return (ops.conv2d_fwd_raw(xg, wt, b.to(dev), 1, 1, None), ops.conv2d_fwd_raw(xg, wt, b.to(dev), 1, 1, 0.2),
+                ops.conv2d_fwd_raw(xg, wt, None, 1, 1, None), ops.conv2d_dgrad_raw(dy, wd, dshape, 1, 1, r),
+                ops.conv2d_dgrad_raw(dy, wd, dshape, 1, 1, r, am, 0.2), ops.conv2d_dgrad_raw(dy, wd, dshape, 1, 1))
+    with ops.conv_math('bf16x3'):
+        try:
+            lib.srhip_debug_set(0, -1)
+            ref = run()
+            lib.srhip_debug_set(0, -2)
+            lib.srhip_debug_set(5, -1)
+            lib.srhip_debug_set(10, 0)
+            classic = run()                      # the 2 x 2 wave grid: bit-identical to the DMA kernel
+            for a, bb in zip(ref, classic):
+                assert torch.equal(a, bb)
+            lib.srhip_debug_set(10, 1)
+            for rep in range(2):
+                got = run()
+                for i, (a, bb) in enumerate(zip(ref, got)):
+                    assert _rel(bb, a) < 2e-6, (i, _rel(bb, a))
+                assert not all(torch.equal(a, bb) for a, bb in zip(ref, got)), 'the K-split kernel did not run'
+        finally:
+            lib.srhip_debug_set(10, 1)
+            lib.srhip_debug_set(0, 0)
+            lib.srhip_debug_set(5, 0)
+    ref64 = F.conv2d(x.double(), wt.detach().cpu().double(), b.double(), padding=1)
+    assert _rel(got[0], ref64) < 5e-6
+    ref64d = torch.nn.grad.conv2d_input(dshape, wd.detach().cpu().double(), dy.cpu().double(), padding=1)
+    assert _rel(got[5], ref64d) < 5e-6
 
 
 @pytest.mark.parametrize('case', [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256),

@@ -53,30 +53,39 @@ def _run_hip(batch, iters, tag, debug=()):
         return scal, grads, (hg, hd)
     finally:
         for key, _ in debug:
-            lib.srhip_debug_set(key, 0)
+            lib.srhip_debug_set(key, 1 if key in (8, 10) else 0)      # (keys 8 and 10 default to 1)
 
 
 def test_bench_configuration_step_b12_against_oracle_and_pinned_kernels():
     B, tag = 12, 'bench_b12'
     scal, grads, (hg, hd) = _run_hip(B, 2, tag)
-    # the same job on the kernel family the small tests pin (bit-identical fprop/dgrad by construction; the generic
-    # split-K wgrad sums in a different order)
+    # the same job (a) with the 64-wide one-tile patch kernel in its bit-identical 2 x 2 form instead of the K-split form
+    # (srhip_debug_set(10, 0)) and (b) on the kernel family the small tests pin: (a) and (b) have bit-identical fprop / dgrad by
+    # construction (the generic split-K wgrad sums in a different order), so they must agree tightly; the K-split kernel groups
+    # its sums differently (1e-6 relative per activation), which near-ties of the 48 arg-max poolings turn into a few
+    # re-routed gradients: a looser bar between the default and (a), the oracle bars below hold for the default
+    scal_c, grads_c, _ = _run_hip(B, 2, tag, debug=((10, 0),))
     scal_p, grads_p, _ = _run_hip(B, 2, tag, debug=((0, 23), (1, 7)))
-    for it in range(2):
-        d = float(np.abs(scal[it] - scal_p[it]).max())
-        print('b12 it %d: scalars vs pinned kernels max diff %.3e' % (it, d))
-        assert d <= 1e-5 * max(1.0, float(np.abs(scal_p[it]).max())), (it, scal[it], scal_p[it])
-    worst = 0.0
-    for net in ('G.', 'D.'):
-        keys = [k for k in grads if k.startswith(net)]
-        net_scale = max(float(grads_p[k].abs().max()) for k in keys)
-        for k in keys:
-            if k.endswith(('key_conv.bias',)) or any(k == 'D.model.%d.bias' % i for i in (2, 5, 8, 11, 14, 19, 22)):
-                continue                                            # identically zero gradients: roundoff only
-            d = float((grads[k] - grads_p[k]).abs().max())
-            worst = max(worst, d / max(float(grads_p[k].abs().max()), 1e-2 * net_scale))
-    print('b12: first-iteration gradients vs pinned kernels, worst score %.3e' % worst)
-    assert worst <= 1e-4, worst
+
+    def compare(sa, ga, sb, gb, what, sbar, gbar):
+        for it in range(2):
+            d = float(np.abs(sa[it] - sb[it]).max())
+            print('b12 it %d: scalars %s max diff %.3e' % (it, what, d))
+            assert d <= sbar * max(1.0, float(np.abs(sb[it]).max())), (what, it, sa[it], sb[it])
+        worst = 0.0
+        for net in ('G.', 'D.'):
+            keys = [k for k in ga if k.startswith(net)]
+            net_scale = max(float(gb[k].abs().max()) for k in keys)
+            for k in keys:
+                if k.endswith(('key_conv.bias',)) or any(k == 'D.model.%d.bias' % i for i in (2, 5, 8, 11, 14, 19, 22)):
+                    continue                                            # identically zero gradients: roundoff only
+                d = float((ga[k] - gb[k]).abs().max())
+                worst = max(worst, d / max(float(gb[k].abs().max()), 1e-2 * net_scale))
+        print('b12: first-iteration gradients %s, worst score %.3e' % (what, worst))
+        assert worst <= gbar, (what, worst)
+
+    compare(scal_c, grads_c, scal_p, grads_p, '2x2 patch form vs pinned kernels', 1e-5, 1e-4)
+    compare(scal, grads, scal_c, grads_c, 'default (K-split) vs 2x2 patch form', 1e-4, 3e-2)
     # and against the CPU oracle (identical weights and inputs)
     _, (og, od, of) = build_pair(12, 3, 4, torch.device('cpu'))
     oG = torch.optim.Adam(og.parameters(), lr=2e-4, betas=(0.9, 0.999))
