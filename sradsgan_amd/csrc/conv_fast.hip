@@ -782,6 +782,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
   };
 
+  // prologue DMAs first (whole patch of chunk 0, B tiles of taps 0 and 1): the address tables below are computed under their latency
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
+  issue_b(0, 0, 0);
+  issue_b(1, 1, 0);
+
   // ---- fragment addressing: everything but the patch-buffer parity is fixed for the whole kernel ----
   const int wm = wave >> 1, wn = wave & 1;
   const int khalf = lane >> 5, l31 = lane & 31;
@@ -863,11 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     do_tap(IC<8>(), lastc, cc);
   };
 
-  // prologue: whole patch of chunk 0, B tiles of taps 0 and 1; convert the patch once B tile 0 (issued after it) is in
-#pragma unroll
-  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
-  issue_b(0, 0, 0);
-  issue_b(1, 1, 0);
+  // (prologue DMAs: issued above, before the fragment tables) convert the patch once B tile 0 (issued after it) is in
   wait_vmcnt<BPW>();
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
@@ -1006,6 +1008,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     *reinterpret_cast<bf16x8_t*>(slot) = odd ? lo : hi;
   };
 
+  // prologue DMAs first -- the patch of chunk 0, the weight tiles of taps 0..3 --, so that the address tables below (54 offsets,
+  // two integer divisions per row) are computed under their latency: every block of a one-round launch pays this prologue at
+  // the same time, with nothing else on the chip to hide it
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
+  issue_b(0, 0, 0);
+  issue_b(1, 1, 0);
+  issue_b(2, 2, 0);
+  issue_b(3, 3, 0);
+
   // ---- fragment addressing by STEP: this wave's tap at step s of a chunk pair is T = 2 s + wk (chunk T / 9, tap T % 9) ----
   const int wm = wave >> 1, wk = wave & 1;
   const int khalf = lane >> 5, l31 = lane & 31;
@@ -1109,13 +1121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     do_step(IC<8>(), lastc, cc0);
   };
 
-  // prologue: the patch of chunk 0, the weight tiles of taps 0..3; the patch is converted once it is in (the tiles stay in flight)
-#pragma unroll
-  for (int k = 0; k < MAXP; ++k) issue_a(0, k, 0);
-  issue_b(0, 0, 0);
-  issue_b(1, 1, 0);
-  issue_b(2, 2, 0);
-  issue_b(3, 3, 0);
+  // (prologue DMAs: issued above, before the fragment tables) the patch is converted once it is in; the weight tiles stay in flight
   wait_vmcnt<4>();
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
