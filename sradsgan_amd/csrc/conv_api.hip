@@ -63,6 +63,7 @@ extern int g_fast_ablate;
 extern int g_conv_math;
 extern int g_sgam_cfg;
 extern int g_pers_grid;
+extern int g_pers_small;
 extern int g_pers_abl;
 }
 extern int g_tail_dbg;
@@ -174,6 +175,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 10) {
     g_patch_ks = value;
+    return SRHIP_OK;
+  }
+  if (key == 11) {
+    g_pers_small = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   wait_vmcnt<0>();                                  // the zero-fill DMAs of the tile that does not exist
 }
 
+int g_pers_small = 1;   // srhip_debug_set(11, v): 0 = launches with fewer tiles than block slots keep the one-tile kernels
 int g_pers_grid = 0;      // srhip_debug_set(5, n)
 int g_pers_abl = 0;       // srhip_debug_set(6, bits): timing-only ablations of conv_patch_pers_kernel<128, bias+lrelu>
 static int g_num_cu = 0;
@@ -536,8 +537,27 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
   const long ntiles = (long)nbm * nbn;
   int slots = 3 * num_cu();
   slots -= slots % 8;                               // keeps a block's XCD (blockIdx % 8) fixed over its tiles
-  if (g_pers_grid < 0 || (g_pers_grid == 0 && ntiles <= slots)) return -1;   // one tile per block: nothing to pipeline
-  const int grid = g_pers_grid > 0 ? (int)(g_pers_grid < ntiles ? g_pers_grid : ntiles) : slots;
+  if (g_pers_grid < 0) return -1;
+  // Fewer tiles than block slots (round 4, srhip_debug_set(11, 0) = the one-tile kernels of rounds 1-3 instead): this kernel still
+  // wins -- bias in LDS, staged non-temporal epilogue, counted waits -- with ONE tile per block for the 64-wide tile (768 tiles at
+  // B = 32: 74.5 against 77.8 us for the K-split one-tile kernel, 384 tiles at B = 16: 45.6 against 48.0), and for the 128-wide
+  // tile with two blocks per CU walking <= 2 tiles each (729 tiles at B = 16: 39.2 us against 42.3 one-tile and 43.9 with 729
+  // blocks: two resident blocks that pipeline beat three that start and end together).  `profiles/r04_patch_pers_small_grids.txt`
+  int grid;
+  if (g_pers_grid > 0) {
+    grid = (int)(g_pers_grid < ntiles ? g_pers_grid : ntiles);
+  } else if (ntiles > slots) {
+    grid = slots;
+  } else if (!g_pers_small) {
+    return -1;
+  } else if (!wide) {
+    grid = (int)ntiles;
+  } else if (ntiles > 2 * (slots / 3)) {
+    grid = 2 * (slots / 3);
+    grid -= grid % 8;
+  } else {
+    return -1;
+  }
   const unsigned db = (unsigned)dbytes;
 #define SRHIP_PP(BN_, EPI_, PROD_)                                                                                      \
   do {                                                                                                                  \

@@ -53,7 +53,7 @@ def _run_hip(batch, iters, tag, debug=()):
         return scal, grads, (hg, hd)
     finally:
         for key, _ in debug:
-            lib.srhip_debug_set(key, 1 if key in (8, 10) else 0)      # (keys 8 and 10 default to 1)
+            lib.srhip_debug_set(key, 1 if key in (8, 10, 11) else 0)      # (keys 8, 10 and 11 default to 1)
 
 
 def test_bench_configuration_step_b12_against_oracle_and_pinned_kernels():

@@ -24,7 +24,10 @@ ops_ = {
     'conv1 fprop 64->256 bias+lrelu': lambda: ops.conv2d_fwd_raw(x64, w1, b1, 1, 1, 0.2),
     'conv2 dgrad 64->256 actmask': lambda: ops.conv2d_dgrad_raw(x64, w2, tuple(t256.shape), 1, 1, None, t256, 0.2),
     'conv2 fprop 256->64': lambda: ops.conv2d_fwd_raw(t256, w2, None, 1, 1, None),
+    'conv1 dgrad 256->64 +skip': lambda: ops.conv2d_dgrad_raw(t256, w1, tuple(x64.shape), 1, 1, x64),
 }
+if os.environ.get('OPS'):
+    ops_ = {k: v for k, v in ops_.items() if any(t in k for t in os.environ['OPS'].split(','))}
 with ops.conv_math(os.environ.get('MODE', 'bf16x3')):
     for name, fn in ops_.items():
         lib.srhip_debug_set(5, -1)
