@@ -214,6 +214,27 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
 int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, const float* fc2, const float* w7,
                          const float* wc_packed, const float* bc, float* out, void* workspace, size_t workspace_bytes, int n, int h,
                          int w, int c, int hidden, void* stream);
+/* ABI 8 -- the CLAM pooling partials (sradsgan.py:108-121: adaptive avg / max pool of the RAB conv2 output) as an object of their
+ * own, so that the conv that PRODUCES u can leave them behind from its epilogue instead of a separate pass over u.
+ * pool = three sections [sum | NaN-propagating max | first arg-max pixel (int32)] of pool_sec_bytes each, [image][segment][64]
+ * inside a section; pool_sec_bytes >= n * srhip_clam_pool_max_segments() * 64 * 4, a multiple of 16.
+ *   srhip_conv2d_fwd_pool   : stride-1 pad-1 3x3 conv to 64 dense channels (flags 0 or SRHIP_EPI_BIAS) + the partials of its output;
+ *                             *nseg_out = segments per image written (epilogue of the persistent patch kernel: 2 x tiles per image;
+ *                             any other kernel: srhip_clam_pool_partial on y, srhip_clam_pool_segments() segments)
+ *   srhip_clam_pool_partial : the stand-alone pooling pass (what srhip_attn_tail_fwd / _eval run internally)
+ *   srhip_attn_tail_fwd_pooled / srhip_attn_tail_eval_pooled: srhip_attn_tail_fwd / _eval without their pooling pass.          */
+int srhip_clam_pool_segments(void);
+int srhip_clam_pool_max_segments(void);
+int srhip_clam_pool_partial(const float* u, float* pool, size_t pool_sec_bytes, int n, int h, int w, int c, void* stream);
+int srhip_conv2d_fwd_pool(const float* x, const float* packed, const float* bias, float* y, float* pool, size_t pool_sec_bytes,
+                          int* nseg_out, int n, int h, int w, int cin, int cout, int ldx, int ldy, int flags, void* stream);
+int srhip_attn_tail_fwd_pooled(const float* u, const float* pool, size_t pool_sec_bytes, int nseg, const float* fc1, const float* fc2,
+                               const float* w7, float* avg, float* mx, int* argmax_hw, float* s, float* pooled, int* argc, float* m,
+                               int n, int h, int w, int c, int hidden, void* stream);
+int srhip_attn_tail_eval_pooled(const float* u, const float* skip, const float* pool, size_t pool_sec_bytes, int nseg, const float* fc1,
+                                const float* fc2, const float* w7, const float* wc_packed, const float* bc, float* out, int n, int h,
+                                int w, int c, int hidden, void* stream);
+
 /* backward, spatial half: dz = gradient at z (dgrad of the 1x1 conv).  Outputs du (partial: s * dy),
  * ds [N][64] (gradient at s), dw7 [2*7*7].  The caller back-propagates ds through sigmoid + MLP
  * (tiny, [N,64]) to davg/dmax and finishes with srhip_attn_tail_bwd_channel (in place on du).      */

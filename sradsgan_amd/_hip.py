@@ -92,6 +92,12 @@ SIGNATURES = {
     'srhip_bn_train_bwd': (_i, [_vp] * 10 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_bwd2_workspace': (_sz, [_l, _i]),
     'srhip_bn_train_bwd_bwd': (_i, [_vp] * 11 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_clam_pool_segments': (_i, []),
+    'srhip_clam_pool_max_segments': (_i, []),
+    'srhip_clam_pool_partial': (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    'srhip_conv2d_fwd_pool': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp] + [_i] * 8 + [_vp]),
+    'srhip_attn_tail_fwd_pooled': (_i, [_vp, _vp, _sz, _i] + [_vp] * 10 + [_i] * 5 + [_vp]),
+    'srhip_attn_tail_eval_pooled': (_i, [_vp, _vp, _vp, _sz, _i] + [_vp] * 6 + [_i] * 5 + [_vp]),
     'srhip_sum_n': (_i, [_vp, _i, _vp, _l, _vp]),
     'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),

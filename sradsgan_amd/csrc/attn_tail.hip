@@ -104,14 +104,14 @@ __global__ __launch_bounds__(256) void clam_mlp_kernel(const float* __restrict__
                                                         const int* __restrict__ parg, const float* __restrict__ fc1,
                                                         const float* __restrict__ fc2, float* __restrict__ avg,
                                                         float* __restrict__ mx, int* __restrict__ arg,
-                                                        float* __restrict__ s, int hw, int hidden) {
+                                                        float* __restrict__ s, int hw, int hidden, int nseg) {
   __shared__ float sa[TC], sm[TC], ha[16], hm[16], qs[4][TC], qm[4][TC];
   __shared__ int qa[4][TC];
   const int b = blockIdx.x, c = threadIdx.x & 63, q = threadIdx.x >> 6;
   float sum = 0.f, m = -INFINITY;
   int am = 0x7fffffff;
-  for (int k = q; k < SEG; k += 4) {
-    const int o = (b * SEG + k) * TC + c;
+  for (int k = q; k < nseg; k += 4) {                // nseg: SEG from clam_pool_partial_kernel, 2 x tiles per image from the conv epilogue
+    const int o = (b * nseg + k) * TC + c;
     sum += psum[o];
     const float v = pmax[o];
     const int a = parg[o];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __r
                                                              const float* __restrict__ fc1, const float* __restrict__ fc2,
                                                              const float* __restrict__ w7, const float* __restrict__ wsplit,
                                                              const float* __restrict__ bc, float* __restrict__ out, int h, int w,
-                                                             int hidden, int PH, int PW, int tiles_h, int tiles_w, int dbg) {
+                                                             int hidden, int PH, int PW, int tiles_h, int tiles_w, int dbg, int nseg) {
   __shared__ __attribute__((aligned(16))) char a_img[128 * EV_PITCH];      // s*u of the tile, split hi|lo per 8 channels
   __shared__ __attribute__((aligned(16))) char w_img[TC * EV_PITCH];       // Wc, split when it was packed
   __shared__ float2 pooled_s[EV_MAXREG];
@@ -612,12 +612,14 @@ __global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __r
   // dependent instruction (the partials, this thread's fc1 row quad, this channel's fc2 row) ----
   {
     const int c = tid & 63, q = tid >> 6;
-    float pv[SEG / 4], pm[SEG / 4];
+    constexpr int PSEG = 64 / 4;                      // up to 64 partial segments per image (POOL_MAXSEG), nseg of them live
+    float pv[PSEG], pm[PSEG];
 #pragma unroll
-    for (int i = 0; i < SEG / 4; ++i) {
-      const int o = (b * SEG + q + 4 * i) * TC + c;
-      pv[i] = psum[o];
-      pm[i] = pmax[o];
+    for (int i = 0; i < PSEG; ++i) {
+      const bool live = q + 4 * i < nseg;
+      const int o = (b * nseg + (live ? q + 4 * i : 0)) * TC + c;
+      pv[i] = live ? psum[o] : 0.f;
+      pm[i] = live ? pmax[o] : -INFINITY;
     }
     const int j = tid >> 4, part = tid & 15;
     float w1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -630,8 +632,8 @@ __global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __r
     for (int jj = 0; jj < 16; ++jj) w2[jj] = (q == 0 && jj < hidden) ? fc2[c * hidden + jj] : 0.f;
     float sum = 0.f, m = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < SEG / 4; ++i) {
-      sum += pv[i];
+    for (int i = 0; i < PSEG; ++i) {
+      if (q + 4 * i < nseg) sum += pv[i];            // (the same additions in the same order as clam_mlp_kernel's loop)
       if (pool_takes(pm[i], m)) m = pm[i];           // values only matter here: a NaN wins, else the maximum
     }
     qs[q][c] = sum;
@@ -803,6 +805,17 @@ extern "C" {
 
 size_t srhip_attn_tail_workspace(int n) { return (size_t)n * (SEG > TAIL_BLK ? SEG : TAIL_BLK) * TC * 3 * sizeof(float); }
 
+static int tail_fwd_impl(const float* u, const float* psum, const float* pmax, const int* parg, int nseg, const float* fc1, const float* fc2,
+                         const float* w7, float* avg, float* mx, int* argmax_hw, float* s, float* pooled, int* argc, float* m, int n, int h,
+                         int w, int hidden, hipStream_t st) {
+  const int hw = h * w;
+  const long npix = (long)n * hw;
+  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(256), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden, nseg);
+  hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
+  hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
+  return check_launch("attn_tail_fwd");
+}
+
 int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, const float* w7, float* avg, float* mx,
                         int* argmax_hw, float* s, float* pooled, int* argc, float* m, void* workspace,
                         size_t workspace_bytes, int n, int h, int w, int c, int hidden, void* stream) {
@@ -810,16 +823,46 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
   SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_fwd: C must be 64, hidden <= 16");
   SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_workspace(n), "attn_tail_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
-  const int hw = h * w;
-  const long npix = (long)n * hw;
   float* psum = static_cast<float*>(workspace);
   float* pmax = psum + (size_t)n * SEG * TC;
   int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
-  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, hw);
-  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(256), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden);
-  hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
-  hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
-  return check_launch("attn_tail_fwd");
+  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, h * w);
+  return tail_fwd_impl(u, psum, pmax, parg, SEG, fc1, fc2, w7, avg, mx, argmax_hw, s, pooled, argc, m, n, h, w, hidden, st);
+}
+
+/* ABI 8: the CLAM pooling partials as an object of their own.  `pool` = three sections [sum | max | first arg-max pixel] of
+ * pool_sec_bytes each, [image][segment][64] inside a section; srhip_clam_pool_partial fills it with srhip_clam_pool_segments()
+ * segments per image, srhip_conv2d_fwd_pool (conv_api.hip) lets the producing conv's epilogue fill it; the *_pooled tails consume it. */
+int srhip_clam_pool_segments(void) { return SEG; }
+int srhip_clam_pool_max_segments(void) { return POOL_MAXSEG; }
+
+static bool pool_sections(const float* pool, size_t sec_bytes, int n, int nseg, const float** psum, const float** pmax, const int** parg) {
+  if (!pool || nseg < 1 || nseg > POOL_MAXSEG || sec_bytes % 16 != 0 || (size_t)n * nseg * TC * sizeof(float) > sec_bytes) return false;
+  *psum = pool;
+  *pmax = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pool) + sec_bytes);
+  *parg = reinterpret_cast<const int*>(reinterpret_cast<const char*>(pool) + 2 * sec_bytes);
+  return true;
+}
+
+int srhip_clam_pool_partial(const float* u, float* pool, size_t pool_sec_bytes, int n, int h, int w, int c, void* stream) {
+  const float *psum, *pmax;
+  const int* parg;
+  SRHIP_REQUIRE(u && c == TC && n > 0 && h > 0 && w > 0 && pool_sections(pool, pool_sec_bytes, n, SEG, &psum, &pmax, &parg),
+                "clam_pool_partial: C must be 64, three 16-byte aligned sections of n * segments * 64 floats");
+  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, as_stream(stream), u, const_cast<float*>(psum),
+                     const_cast<float*>(pmax), const_cast<int*>(parg), h * w);
+  return check_launch("clam_pool_partial");
+}
+
+int srhip_attn_tail_fwd_pooled(const float* u, const float* pool, size_t pool_sec_bytes, int nseg, const float* fc1, const float* fc2,
+                               const float* w7, float* avg, float* mx, int* argmax_hw, float* s, float* pooled, int* argc, float* m,
+                               int n, int h, int w, int c, int hidden, void* stream) {
+  const float *psum, *pmax;
+  const int* parg;
+  SRHIP_REQUIRE(u && fc1 && fc2 && w7 && avg && mx && argmax_hw && s && pooled && argc && m, "attn_tail_fwd_pooled: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_fwd_pooled: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(pool_sections(pool, pool_sec_bytes, n, nseg, &psum, &pmax, &parg), "attn_tail_fwd_pooled: bad pooling partials");
+  return tail_fwd_impl(u, psum, pmax, parg, nseg, fc1, fc2, w7, avg, mx, argmax_hw, s, pooled, argc, m, n, h, w, hidden, as_stream(stream));
 }
 
 /* Inference form of the tail (round 4, ABI 6): out = conv1x1(SLAM(CLAM(u))) + bc + skip in two launches (pooling partials, then one
@@ -827,19 +870,9 @@ int srhip_attn_tail_fwd(const float* u, const float* fc1, const float* fc2, cons
  * conv (srhip_pack_weight, mode 0: the split-bf16 section is read), bc may be NULL.  Split-bf16 arithmetic only (the caller takes
  * srhip_attn_tail_fwd + srhip_conv2d_fwd in the other modes); bit-identical to that pair in split-bf16.
  * Replaces: the eval-mode forward of sradsgan.py:254-274 / 303-323.                                                          */
-int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, const float* fc2, const float* w7,
-                         const float* wc_packed, const float* bc, float* out, void* workspace, size_t workspace_bytes, int n, int h,
-                         int w, int c, int hidden, void* stream) {
-  SRHIP_REQUIRE(u && skip && fc1 && fc2 && w7 && wc_packed && out, "attn_tail_eval: null tensor");
-  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_eval: C must be 64, hidden <= 16");
-  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_workspace(n), "attn_tail_eval: workspace too small");
-  SRHIP_REQUIRE(srhip_get_conv_math() == SRHIP_MATH_BF16X3, "attn_tail_eval: split-bf16 arithmetic only");
-  SRHIP_REQUIRE(((((uintptr_t)u) | ((uintptr_t)skip) | ((uintptr_t)out) | ((uintptr_t)wc_packed) | ((uintptr_t)bc)) & 15) == 0, "attn_tail_eval: 16-byte aligned tensors");
-  hipStream_t st = as_stream(stream);
-  const int hw = h * w;
-  float* psum = static_cast<float*>(workspace);
-  float* pmax = psum + (size_t)n * SEG * TC;
-  int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
+static int tail_eval_impl(const float* u, const float* skip, const float* psum, const float* pmax, int nseg, const float* fc1,
+                          const float* fc2, const float* w7, const float* wc_packed, const float* bc, float* out, int n, int h, int w,
+                          int hidden, hipStream_t st) {
   // tile: PH x PW <= 128 pixels, pooled region (PH + 6) x (PW + 6) <= EV_MAXREG, fewest dead rows over the image
   int PH = 1, PW = 1;
   double best = -1.0;
@@ -855,10 +888,38 @@ int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, co
     }
   }
   const int tiles_h = cdiv(h, PH), tiles_w = cdiv(w, PW);
-  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, hw);
   hipLaunchKernelGGL(attn_tail_eval_kernel, dim3(n * tiles_h * tiles_w), dim3(256), 0, st, u, skip, psum, pmax, fc1, fc2, w7,
-                     wc_packed + (size_t)TC * TC, bc, out, h, w, hidden, PH, PW, tiles_h, tiles_w, g_tail_dbg);
+                     wc_packed + (size_t)TC * TC, bc, out, h, w, hidden, PH, PW, tiles_h, tiles_w, g_tail_dbg, nseg);
   return check_launch("attn_tail_eval");
+}
+
+int srhip_attn_tail_eval(const float* u, const float* skip, const float* fc1, const float* fc2, const float* w7,
+                         const float* wc_packed, const float* bc, float* out, void* workspace, size_t workspace_bytes, int n, int h,
+                         int w, int c, int hidden, void* stream) {
+  SRHIP_REQUIRE(u && skip && fc1 && fc2 && w7 && wc_packed && out, "attn_tail_eval: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_eval: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_workspace(n), "attn_tail_eval: workspace too small");
+  SRHIP_REQUIRE(srhip_get_conv_math() == SRHIP_MATH_BF16X3, "attn_tail_eval: split-bf16 arithmetic only");
+  SRHIP_REQUIRE(((((uintptr_t)u) | ((uintptr_t)skip) | ((uintptr_t)out) | ((uintptr_t)wc_packed) | ((uintptr_t)bc)) & 15) == 0, "attn_tail_eval: 16-byte aligned tensors");
+  hipStream_t st = as_stream(stream);
+  float* psum = static_cast<float*>(workspace);
+  float* pmax = psum + (size_t)n * SEG * TC;
+  int* parg = reinterpret_cast<int*>(pmax + (size_t)n * SEG * TC);
+  hipLaunchKernelGGL(clam_pool_partial_kernel, dim3(n * SEG), dim3(256), 0, st, u, psum, pmax, parg, h * w);
+  return tail_eval_impl(u, skip, psum, pmax, SEG, fc1, fc2, w7, wc_packed, bc, out, n, h, w, hidden, st);
+}
+
+int srhip_attn_tail_eval_pooled(const float* u, const float* skip, const float* pool, size_t pool_sec_bytes, int nseg, const float* fc1,
+                                const float* fc2, const float* w7, const float* wc_packed, const float* bc, float* out, int n, int h,
+                                int w, int c, int hidden, void* stream) {
+  const float *psum, *pmax;
+  const int* parg;
+  SRHIP_REQUIRE(u && skip && fc1 && fc2 && w7 && wc_packed && out, "attn_tail_eval_pooled: null tensor");
+  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_eval_pooled: C must be 64, hidden <= 16");
+  SRHIP_REQUIRE(pool_sections(pool, pool_sec_bytes, n, nseg, &psum, &pmax, &parg), "attn_tail_eval_pooled: bad pooling partials");
+  SRHIP_REQUIRE(srhip_get_conv_math() == SRHIP_MATH_BF16X3, "attn_tail_eval_pooled: split-bf16 arithmetic only");
+  SRHIP_REQUIRE(((((uintptr_t)u) | ((uintptr_t)skip) | ((uintptr_t)out) | ((uintptr_t)wc_packed) | ((uintptr_t)bc)) & 15) == 0, "attn_tail_eval_pooled: 16-byte aligned tensors");
+  return tail_eval_impl(u, skip, psum, pmax, nseg, fc1, fc2, w7, wc_packed, bc, out, n, h, w, hidden, as_stream(stream));
 }
 
 size_t srhip_attn_tail_bwd_workspace(int n, int h, int w) {

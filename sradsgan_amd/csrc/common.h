@@ -55,4 +55,6 @@ __device__ __forceinline__ bool pool_merge_takes(float om, int oi, float mx, int
   return om > mx || (om == mx && oi < idx);
 }
 
+constexpr int POOL_MAXSEG = 64;   // most CLAM pooling partial segments per image (attn_tail.hip consumers, conv epilogue producer)
+
 }  // namespace srhip

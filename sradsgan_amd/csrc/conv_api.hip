@@ -2,6 +2,7 @@
 // choice between the fast kernels (conv_fast.hip) and the generic implicit-GEMM (conv_igemm.hip).
 // The choice depends only on the conv's static shape, so srhip_pack_weight and srhip_conv2d_* agree.
 #include "conv_internal.h"
+#include "conv_dev.h"
 
 using namespace srhip;
 
@@ -244,6 +245,35 @@ int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, con
   SRHIP_REQUIRE(!(flags & SRHIP_EPI_CHANSCALE), "conv2d_fwd: EPI_CHANSCALE needs Cin % 16 == 0");
   return legacy_conv2d_fwd(x, packed, bias, residual, rowscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy,
                            ldr, slope, flags, stream);
+}
+
+/* ABI 8: a stride-1 3x3 conv to 64 channels (RAB conv2, sradsgan.py:223) that also leaves the CLAM pooling partials of its
+ * output (per channel: sum, NaN-propagating maximum, first arg-max pixel; sradsgan.py:108-121) in `pool`: from the conv's own
+ * epilogue when the persistent patch kernel takes the launch, else by srhip_clam_pool_partial on y.  *nseg_out = partial segments
+ * per image written (the *_pooled tails take it).  pool: three sections of pool_sec_bytes >= n * srhip_clam_pool_max_segments()
+ * * 64 * 4 bytes.  flags: 0 or SRHIP_EPI_BIAS.                                                                                  */
+int srhip_conv2d_fwd_pool(const float* x, const float* packed, const float* bias, float* y, float* pool, size_t pool_sec_bytes,
+                          int* nseg_out, int n, int h, int w, int cin, int cout, int ldx, int ldy, int flags, void* stream) {
+  SRHIP_REQUIRE(x && packed && y && pool && nseg_out, "conv2d_fwd_pool: null tensor");
+  SRHIP_REQUIRE(cout == 64 && ldy == 64 && n > 0 && h > 0 && w > 0 && cin > 0 && ldx >= cin, "conv2d_fwd_pool: 64 dense destination channels");
+  SRHIP_REQUIRE((flags & ~SRHIP_EPI_BIAS) == 0 && (!(flags & SRHIP_EPI_BIAS) || bias), "conv2d_fwd_pool: plain or bias epilogue");
+  SRHIP_REQUIRE(pool_sec_bytes % 16 == 0 && pool_sec_bytes < (1u << 30) && (((uintptr_t)pool) & 15) == 0 &&
+                    pool_sec_bytes >= (size_t)n * POOL_MAXSEG * 64 * sizeof(float),
+                "conv2d_fwd_pool: three 16-byte aligned sections of n * max_segments * 64 floats");
+  g_pool_req.out = pool;
+  g_pool_req.sec_bytes = (unsigned)pool_sec_bytes;
+  g_pool_req.served_nseg = 0;
+  const int rc = srhip_conv2d_fwd(x, packed, bias, nullptr, nullptr, nullptr, y, n, h, w, cin, cout, 3, 3, 1, 1, ldx, ldy, 0, 0.f, flags, stream);
+  const int served = g_pool_req.served_nseg;
+  g_pool_req.out = nullptr;
+  g_pool_req.served_nseg = 0;
+  if (rc != SRHIP_OK) return rc;
+  if (served > 0) {
+    *nseg_out = served;
+    return SRHIP_OK;
+  }
+  *nseg_out = srhip_clam_pool_segments();
+  return srhip_clam_pool_partial(y, pool, pool_sec_bytes, n, h, w, cout, stream);
 }
 
 int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,

@@ -144,6 +144,15 @@ __device__ __forceinline__ void patch_pixel(int r, int PH, int PW, unsigned gmap
 }
 
 // conv_patch_pers.hip: persistent tile-walking form of conv_patch_kernel; -1 = not applicable (caller launches conv_patch_kernel)
+// A pooling request rides beside ONE forward conv call (srhip_conv2d_fwd_pool, conv_api.hip): the persistent patch kernel serves it
+// from its epilogue when the geometry allows (64 destination channels, <= POOL_MAXSEG / 2 tiles per image) and reports the number of
+// partial segments per image it wrote; otherwise the caller runs the stand-alone pooling kernel.  thread_local: one request per calling thread.
+struct PoolRequest {
+  float* out = nullptr;            // [sum | max | arg] sections of sec_bytes each, [image][segment][64] inside a section
+  unsigned sec_bytes = 0;
+  int served_nseg = 0;             // set by the kernel launch that served the request
+};
+extern thread_local PoolRequest g_pool_req;
 int launch_patch_pers(const float* src, const float* wt, const float* bias, const float* residual, const float* actmask,
                       float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
                       hipStream_t st);

@@ -36,11 +36,16 @@ extern int g_fast_ablate;
 
 // ABL: timing-only ablations (wrong results), srhip_debug_set(6, bits) on the <128, bias+lrelu> fprop: 1 stores dropped (out-of-range
 // offsets: issued, never written), 2 no in-place conversion, 4 no MFMAs, 8 no fragment reads, 16 no B DMA in the loop, 32 no epilogue
-template <int BN, int EPI, int PROD = 0, int ABL = 0>
+// POOL (round 4, BN = 64 with K <= 64 only): the epilogue also reduces the tile's final outputs per channel -- sum, NaN-propagating
+// maximum, first arg-max pixel -- and writes one partial per (image, tile, wave row): the CLAM pooling partials of the RAB tail
+// (clam_pool_partial_kernel's job: a 24 MB read and a launch per RAB) as three more counted stores of the producing conv.
+// pool_out: [3 sections: sum | max | arg][image][2 * tiles per image][64], section stride pool_sec bytes.
+template <int BN, int EPI, int PROD = 0, int ABL = 0, int POOL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_pers_kernel(
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
-    PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16) {
+    PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16, float* __restrict__ pool_out, unsigned pool_sec) {
+  static_assert(POOL == 0 || (BN == 64 && PROD == 0 && ABL == 0), "pooling epilogue: 64-wide tile, split-bf16");
   constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int XB = (ABL & 128) ? 2 : 1, XA = (ABL & 256) ? 2 : 1;   // ablations 128 / 256: every B / A DMA issued twice (marginal cost of the streams)
   constexpr bool DIRECT = (ABL & 64) != 0;          // ablation 64: epilogue straight from the accumulators with the MFMA operand roles swapped (see the header)
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   constexpr int LDS_B = 2 * PATCH_B + 3 * BSTAGE_B;
   constexpr int QPRW = WTN / 4;                     // float4s per staged row
   constexpr int NRD = 16 * QPRW / 64;               // float4s per lane per 16-row pass
-  constexpr int NS = 4 * NRD;                       // epilogue stores per wave per tile (always issued)
+  constexpr int NS = 4 * NRD + (POOL ? 3 : 0);      // epilogue stores per wave per tile (always issued); POOL: + sum, max, arg partials
   constexpr int STG_B = 16 * WTN * 4;               // staging bytes per wave
   static_assert(3 * STG_B <= PATCH_B && STG_B <= BSTAGE_B, "epilogue staging must fit the released buffers");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, g.src_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(POOL ? pool_out : dst, 0, POOL ? 3u * pool_sec : 0u, 0x00020000);   // pooling partials (POOL)
 
   // ---- per-tile addressing ----
   struct TileAt {
@@ -412,6 +418,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     float4 am[2][NRD];
     unsigned doffs[2][NRD];
     bool oks[2][NRD];
+    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pm[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};   // POOL: this lane's 4 channels over its 8 rows
+    int pa[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     pass_offsets(0, doffs[0], oks[0]);
     if (flags & SRHIP_EPI_ACTMASK) {
 #pragma unroll
@@ -461,8 +469,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         const unsigned eoff = (ok && !(ABL & 1)) ? doff : F_OOB + ((ABL & 1) ? 16u * (unsigned)(p * NRD + i) : 0u);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
+        if (POOL && ok) {                               // pixel index inside the image: the arg-max the backward scatters to
+          const int pt = pix_tab[wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + i * (64 / QPRW) + rsub];
+          const int pidx = (t.oh0 + (pt >> 16)) * g.OW + t.ow0 + (pt & 0xffff);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            ps[c] += vv[c];
+            if (pool_merge_takes(vv[c], pidx, pm[c], pa[c])) {
+              pm[c] = vv[c];
+              pa[c] = pidx;
+            }
+          }
+        }
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (POOL) {
+      // the 8 lanes that serve the same channel quad (lane = rsub * 8 + cq) hold the wave's 64 rows between them: butterfly over
+      // lane bits 3, 4, 5 (a + b == b + a and the (value, index) merge is symmetric: every lane ends with the same result)
+#pragma unroll
+      for (int step = 0; step < 3; ++step) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float os, om;
+          int oa;
+          if (step == 0) {
+            os = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ps[c]), 0x128, 0xF, 0xF, false));   // row_ror:8
+            om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pm[c]), 0x128, 0xF, 0xF, false));
+            oa = __builtin_amdgcn_update_dpp(0, pa[c], 0x128, 0xF, 0xF, false);
+          } else {
+            const int m = step == 1 ? 16 : 32;
+            os = __shfl_xor(ps[c], m, 64);
+            om = __shfl_xor(pm[c], m, 64);
+            oa = __shfl_xor(pa[c], m, 64);
+          }
+          ps[c] += os;
+          if (pool_merge_takes(om, oa, pm[c], pa[c])) {
+            pm[c] = om;
+            pa[c] = oa;
+          }
+        }
+      }
+      const int tin = (t.oh0 / pg.PH) * pg.tiles_w + t.ow0 / pg.PW;            // tile inside the image
+      const unsigned poff = (ln < QPRW && nok) ? (unsigned)(((t.img * tpi + tin) * 2 + wm) * 64 + n) * 4u : F_OOB;
+      const float4 s4 = make_float4(ps[0], ps[1], ps[2], ps[3]), m4 = make_float4(pm[0], pm[1], pm[2], pm[3]);
+      const u32x4 a4 = {(unsigned)pa[0], (unsigned)pa[1], (unsigned)pa[2], (unsigned)pa[3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s4), rs_p, poff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m4), rs_p, poff < F_OOB ? poff + pool_sec : F_OOB + 16u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(a4, rs_p, poff < F_OOB ? poff + 2u * pool_sec : F_OOB + 32u, 0, 0);
     }
     zero_acc();
   };
@@ -503,6 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   wait_vmcnt<0>();                                  // the zero-fill DMAs of the tile that does not exist
 }
 
+thread_local PoolRequest g_pool_req;
 int g_pers_small = 1;   // srhip_debug_set(11, v): 0 = launches with fewer tiles than block slots keep the one-tile kernels
 int g_pers_grid = 0;      // srhip_debug_set(5, n)
 int g_pers_abl = 0;       // srhip_debug_set(6, bits): timing-only ablations of conv_patch_pers_kernel<128, bias+lrelu>
@@ -562,7 +618,7 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
 #define SRHIP_PP(BN_, EPI_, PROD_)                                                                                      \
   do {                                                                                                                  \
     hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, PROD_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,     \
-                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16);                                                    \
+                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16, nullptr, 0u);                                                    \
     return check_launch("conv_patch_pers");                                                                             \
   } while (0)
   if (prod != 0) {
@@ -571,11 +627,28 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
     if (prod == 1) SRHIP_PP(64, -1, 1);
     SRHIP_PP(64, -1, 2);
   }
+  // CLAM pooling partials from the epilogue (srhip_conv2d_fwd_pool): 64 destination channels in one N tile, plain or bias epilogue
+  if (g_pool_req.out != nullptr && !wide && prod == 0 && nbn == 1 && g.K == 64 && (eflags == 0 || eflags == SRHIP_EPI_BIAS) &&
+      2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW) {
+    const int nseg = 2 * pg.tiles_h * pg.tiles_w;
+    if ((size_t)g.N * nseg * 64 * 4 <= (size_t)g_pool_req.sec_bytes) {
+      float* po = g_pool_req.out;
+      const unsigned ps = g_pool_req.sec_bytes;
+      g_pool_req.served_nseg = nseg;
+      if (eflags == 0)
+        hipLaunchKernelGGL((conv_patch_pers_kernel<64, 0, 0, 0, 1>), dim3(grid), dim3(256), 0, st, src, wsplit, bias, residual, actmask, dst, g,
+                           pg, nbm, nbn, db, ndst16, po, ps);
+      else
+        hipLaunchKernelGGL((conv_patch_pers_kernel<64, 1, 0, 0, 1>), dim3(grid), dim3(256), 0, st, src, wsplit, bias, residual, actmask, dst, g,
+                           pg, nbm, nbn, db, ndst16, po, ps);
+      return check_launch("conv_patch_pers_pool");
+    }
+  }
   if (g_pers_abl != 0 && wide && prod == 0 && eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) {
 #define SRHIP_PA(ABL_)                                                                                                  \
   if (g_pers_abl == ABL_) {                                                                                             \
     hipLaunchKernelGGL((conv_patch_pers_kernel<128, 3, 0, ABL_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,      \
-                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16);                                                    \
+                       residual, actmask, dst, g, pg, nbm, nbn, db, ndst16, nullptr, 0u);                                                    \
     return check_launch("conv_patch_pers");                                                                             \
   }
     SRHIP_PA(1) SRHIP_PA(2) SRHIP_PA(4) SRHIP_PA(12) SRHIP_PA(16) SRHIP_PA(32) SRHIP_PA(30) SRHIP_PA(26) SRHIP_PA(63) SRHIP_PA(64) SRHIP_PA(128) SRHIP_PA(256)

@@ -354,6 +354,33 @@ def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=
     return y
 
 
+_POOL_EPI = os.environ.get('SRHIP_POOL_EPI', '1') == '1'      # A/B knob: 0 = the RAB tails run their own pooling pass over u
+
+
+def pool_epilogue_ok(x, w):
+    """RAB conv2 + its CLAM pooling partials in one call (srhip_conv2d_fwd_pool): split-bf16, stride-1 3x3 to 64 channels."""
+    return (_POOL_EPI and x.is_cuda and get_conv_math() == 'bf16x3' and tuple(w.shape[2:]) == (3, 3) and w.shape[0] == 64
+            and w.shape[1] % 32 == 0)
+
+
+def conv2d_fwd_pool_raw(x, w, bias):
+    """y = conv3x3(x, w) + bias (stride 1, pad 1, 64 output channels) and the CLAM pooling partials of y.
+    Returns (y, (pool, section_bytes, nseg)): pool = [sum | max | arg] sections, nseg partial segments per image."""
+    _require_gpu(x, 'conv2d_fwd_pool')
+    x = nhwc(x)
+    n, cin, h, wd = x.shape
+    cout = w.shape[0]
+    y = empty_nhwc(n, cout, h, wd, x)
+    lib = _hip.lib()
+    sec = n * lib.srhip_clam_pool_max_segments() * 64 * 4
+    pool = torch.empty(3 * sec // 4, device=x.device, dtype=torch.float32)
+    nseg = ctypes.c_int(0)
+    b = bias.detach().contiguous() if bias is not None else None
+    _hip.check(lib.srhip_conv2d_fwd_pool(_p(x), _p(packed_weight(w, 0)), _p(b), _p(y), _p(pool), sec, ctypes.byref(nseg), n, h, wd, cin,
+                                         cout, cin, cout, EPI_BIAS if b is not None else 0, _stream()), 'conv2d_fwd_pool')
+    return y, (pool, sec, nseg.value)
+
+
 def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, slope=0.0):
     """dx = conv_transpose(dy, w) [* lrelu'(actmask)] [+ residual]: the optional tail fuses the backward
     of the LeakyReLU that produced this conv's input and the skip-path gradient add."""
@@ -830,8 +857,9 @@ def pixel_shuffle_act(x, r, slope=None):
 _TAIL_FUSED = os.environ.get('SRHIP_TAIL_FUSED', '1') == '1'
 
 
-def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
-    """returns (out, tensors to save for _tail_backward)."""
+def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
+    """returns (out, tensors to save for _tail_backward).  pool: (buffer, section bytes, nseg) from conv2d_fwd_pool_raw -- the
+    pooling partials of u left behind by the conv that produced it (else the tail runs its own pooling pass)."""
     n, c, h, w = u.shape
     lib = _hip.lib()
     dev = u.device
@@ -840,11 +868,16 @@ def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc):
     arg = torch.empty(n, c, device=dev, dtype=torch.int32)
     pooled, m = torch.empty(n * h * w, 2, **f32), torch.empty(n * h * w, **f32)
     argc = torch.empty(n * h * w, device=dev, dtype=torch.int32)
-    ws = torch.empty(lib.srhip_attn_tail_workspace(n) // 4, **f32)
     fc1c, fc2c, w7c = fc1_w.detach().contiguous(), fc2_w.detach().contiguous(), w7.detach().contiguous()
-    _hip.check(lib.srhip_attn_tail_fwd(_p(u), _p(fc1c), _p(fc2c), _p(w7c), _p(avg), _p(mx), _p(arg), _p(s),
-                                       _p(pooled), _p(argc), _p(m), _p(ws), ws.numel() * 4, n, h, w, c,
-                                       fc1_w.shape[0], _stream()), 'attn_tail_fwd')
+    if pool is not None:
+        _hip.check(lib.srhip_attn_tail_fwd_pooled(_p(u), _p(pool[0]), pool[1], pool[2], _p(fc1c), _p(fc2c), _p(w7c), _p(avg), _p(mx), _p(arg),
+                                                  _p(s), _p(pooled), _p(argc), _p(m), n, h, w, c, fc1_w.shape[0], _stream()),
+                   'attn_tail_fwd_pooled')
+    else:
+        ws = torch.empty(lib.srhip_attn_tail_workspace(n) // 4, **f32)
+        _hip.check(lib.srhip_attn_tail_fwd(_p(u), _p(fc1c), _p(fc2c), _p(w7c), _p(avg), _p(mx), _p(arg), _p(s),
+                                           _p(pooled), _p(argc), _p(m), _p(ws), ws.numel() * 4, n, h, w, c,
+                                           fc1_w.shape[0], _stream()), 'attn_tail_fwd')
     out = conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s)
     return out, (avg, mx, arg, s, pooled, argc, m)
 
@@ -901,12 +934,18 @@ def _tail_eval_ok(u):
     return _TAIL_EVAL and not torch.is_grad_enabled() and u.is_cuda and get_conv_math() == 'bf16x3'
 
 
-def _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc):
-    """conv1x1(SLAM(CLAM(u))) + bc + skip with nothing saved: two launches (sradsgan.py:254-274 in eval mode)."""
+def _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
+    """conv1x1(SLAM(CLAM(u))) + bc + skip with nothing saved: two launches (sradsgan.py:254-274 in eval mode), one when the conv
+    that produced u left the pooling partials behind (pool, see _tail_forward)."""
     u, skip = nhwc(u), nhwc(skip)
     n, c, h, w = u.shape
     lib = _hip.lib()
     out = torch.empty_like(u, memory_format=CL)
+    if pool is not None:
+        _hip.check(lib.srhip_attn_tail_eval_pooled(_p(u), _p(skip), _p(pool[0]), pool[1], pool[2], _p(fc1_w.detach().contiguous()),
+                                                   _p(fc2_w.detach().contiguous()), _p(w7.detach().contiguous()), _p(packed_weight(wc, 0)),
+                                                   _p(bc), _p(out), n, h, w, c, fc1_w.shape[0], _stream()), 'attn_tail_eval_pooled')
+        return out
     ws = torch.empty(lib.srhip_attn_tail_workspace(n) // 4, device=u.device, dtype=torch.float32)
     _hip.check(lib.srhip_attn_tail_eval(_p(u), _p(skip), _p(fc1_w.detach().contiguous()), _p(fc2_w.detach().contiguous()),
                                         _p(w7.detach().contiguous()), _p(packed_weight(wc, 0)), _p(bc), _p(out), _p(ws), ws.numel() * 4,
@@ -945,8 +984,11 @@ class _RabBlock(Function):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
         t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
-        u = conv2d_fwd_raw(t, w2, b2, 1, 1)
-        out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc)
+        if pool_epilogue_ok(t, w2):                      # conv2 leaves the CLAM pooling partials of u behind (its epilogue, when the patch walk takes it)
+            u, pool = conv2d_fwd_pool_raw(t, w2, b2)
+        else:
+            u, pool = conv2d_fwd_raw(t, w2, b2, 1, 1), None
+        out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
         ctx.save_for_backward(x, t, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved)
         ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
         return out
@@ -971,8 +1013,12 @@ def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
     if _tail_eval_ok(x):                                 # inference: three conv-sized launches + the pooling partials per block
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
-        u = conv2d_fwd_raw(conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2), w2, b2, 1, 1)
-        return _tail_forward_eval(u, x, fc1_w, fc2_w, w7, wc, bc)
+        t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
+        if pool_epilogue_ok(t, w2):
+            u, pool = conv2d_fwd_pool_raw(t, w2, b2)
+        else:
+            u, pool = conv2d_fwd_raw(t, w2, b2, 1, 1), None
+        return _tail_forward_eval(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
     return _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc)
 
 

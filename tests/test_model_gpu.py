@@ -553,3 +553,59 @@ def test_bus_sum_is_bit_identical_to_chained_adds(n_terms):
     dy = torch.randn(2, 64, 13, 17, generator=g).to(DEV)
     got.backward(dy)
     assert all(torch.equal(t.grad, dy) for t in ts)
+
+
+@pytest.mark.parametrize('shape', [(2, 54, 54), (3, 27, 27), (1, 13, 70), (2, 24, 24), (16, 54, 54)])
+def test_conv_epilogue_pooling_partials_match_the_pooling_pass(shape):
+    """srhip_conv2d_fwd_pool (ABI 8): RAB conv2 leaves the CLAM pooling partials of its output behind -- from the persistent patch
+    kernel's epilogue (one partial per tile and wave row) when that kernel takes the launch, from the stand-alone pooling pass
+    otherwise.  Reduced by the tail's MLP kernel both must give the pass's result: max and first arg-max pixel exactly (the merge
+    is order-independent), the mean to rounding; the conv output itself is the plain call's, bit for bit.  Ragged tiles, tiles
+    that hang over the image, a NaN, and ties (a constant channel: arg-max = pixel 0)."""
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * 1000 + h)
+    t = torch.randn(n, 256, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    w2 = torch.nn.Parameter((torch.randn(64, 256, 3, 3, generator=g) * 0.05).to(DEV))
+    w2.data[5] = 0.0                                                # channel 5: constant (= bias) everywhere: all pixels tie
+    b2 = torch.randn(64, generator=g).to(DEV)
+    fc1 = (torch.randn(4, 64, 1, 1, generator=g) * 0.3).to(DEV)
+    fc2 = (torch.randn(64, 4, 1, 1, generator=g) * 0.3).to(DEV)
+    w7 = (torch.randn(1, 2, 7, 7, generator=g) * 0.2).to(DEV)
+    wc = (torch.randn(64, 64, 1, 1, generator=g) * 0.1).to(DEV)
+    skip = torch.randn(n, 64, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    with ops.conv_math('bf16x3'):
+        lib.srhip_debug_set(0, -2)                                  # small problems: send them to the patch family (the walk takes 64-wide tiles at any count)
+        try:
+            u_ref = ops.conv2d_fwd_raw(t, w2, b2, 1, 1)
+            for grid in (3, 1, 8, 0):                               # blocks that walk MANY tiles: the three extra stores per tile are counted waits like the others
+                lib.srhip_debug_set(5, grid)
+                for rep in range(2):
+                    u, pool = ops.conv2d_fwd_pool_raw(t, w2, b2)
+                    assert torch.equal(u, u_ref), grid
+                    _, sv = ops._tail_forward(u, skip, fc1, fc2, w7, wc, None, pool)
+                    if grid == 3 and rep == 0:
+                        first = sv
+                    assert all(torch.equal(a, b) for a, b in zip(first[:3], sv[:3])), grid
+            assert pool[2] != lib.srhip_clam_pool_segments() or h * w > 64 * 128, 'the epilogue did not serve the request'
+            out_ref, saved_ref = ops._tail_forward(u_ref, skip, fc1, fc2, w7, wc, None)
+            out, saved = ops._tail_forward(u, skip, fc1, fc2, w7, wc, None, pool)
+            avg_r, mx_r, arg_r = saved_ref[0], saved_ref[1], saved_ref[2]
+            avg, mx, arg = saved[0], saved[1], saved[2]
+            assert torch.equal(mx, mx_r) and torch.equal(arg, arg_r)
+            assert int(arg[0, 5]) == 0
+            assert float((avg - avg_r).abs().max()) <= 2e-6 * float(avg_r.abs().max())
+            assert float((out - out_ref).abs().max()) <= 1e-5 * float(out_ref.abs().max())
+            with torch.no_grad():
+                ev = ops._tail_forward_eval(u, skip, fc1, fc2, w7, wc, None, pool)
+            assert float((ev - out_ref).abs().max()) <= 1e-5 * float(out_ref.abs().max())
+            # a NaN input pixel poisons the 3x3 neighbourhood of u in every channel: it must surface in the pooled maximum
+            t2 = t.clone()
+            t2[0, 7, h // 2, w // 2] = float('nan')
+            u2, pool2 = ops.conv2d_fwd_pool_raw(t2, w2, b2)
+            _, saved2 = ops._tail_forward(u2, skip, fc1, fc2, w7, wc, None, pool2)
+            assert torch.isnan(saved2[1][0]).all() and torch.isfinite(saved2[1][1:]).all()
+        finally:
+            lib.srhip_debug_set(0, 0)
+            lib.srhip_debug_set(5, 0)
