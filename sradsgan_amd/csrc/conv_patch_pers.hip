@@ -629,7 +629,11 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
   }
   // CLAM pooling partials from the epilogue (srhip_conv2d_fwd_pool): 64 destination channels in one N tile, plain or bias epilogue
   if (g_pool_req.out != nullptr && !wide && prod == 0 && nbn == 1 && g.K == 64 && (eflags == 0 || eflags == SRHIP_EPI_BIAS) &&
-      2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW) {
+      2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW &&
+      (ntiles <= 2 * (slots / 3) || g_pers_grid > 0)) {
+    // (only while at most two blocks share a CU: the reduction is ~600 VALU instructions per lane and tile at the exposed end of every
+    // block -- with 768 one-tile blocks (B = 32) it adds 5.8 us to the conv, as much as the 24 MB pooling pass it replaces takes;
+    // with 384 (B = 16) 2.8 us against 4.3-5.9: `tools/time_pool_epi.py`.  Larger launches leave the request to the pooling pass.)
     const int nseg = 2 * pg.tiles_h * pg.tiles_w;
     if ((size_t)g.N * nseg * 64 * 4 <= (size_t)g_pool_req.sec_bytes) {
       float* po = g_pool_req.out;
