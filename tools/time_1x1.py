@@ -1,5 +1,6 @@
 """Round 4: the attention tail's 1x1 convs (64 -> 64 at 54 x 54) on their own: forward with bias + residual + both scales, data
-gradient; achieved bandwidth against the bytes they must move."""
+gradient; achieved bandwidth against the bytes they must move.  (A streaming rebuild of these convs -- resident blocks, weights
+as MFMA fragments in registers -- measured no faster and was dropped: profiles/r04_streaming_1x1_rejected.txt.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,10 +30,8 @@ with ops.conv_math('bf16x3'):
         m = torch.rand(B * 54 * 54, device=dev)
         s = torch.rand(B, 64, device=dev)
         mb = B * 64 * 54 * 54 * 4 / 1e6
-        for key in (0, 1, 0, 1):
-            lib.srhip_debug_set(12, key)
+        for rnd in range(2):
             a = t(lambda: ops.conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s))
             b = t(lambda: ops.conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0))
-            print('B=%d %-22s 1x1 fwd (bias, residual, scales): %.1f us = %.2f TB/s of %d MB | 1x1 dgrad: %.1f us = %.2f TB/s of %d MB' % (
-                B, 'streaming kernel' if key else 'DMA GEMM kernel', a, 3 * mb / a, 3 * mb, b, 2 * mb / b, 2 * mb), flush=True)
-lib.srhip_debug_set(12, 1)
+            print('B=%d 1x1 fwd (bias, residual, scales): %.1f us = %.2f TB/s of %d MB | 1x1 dgrad: %.1f us = %.2f TB/s of %d MB' % (
+                B, a, 3 * mb / a, 3 * mb, b, 2 * mb / b, 2 * mb), flush=True)
