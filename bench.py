@@ -181,6 +181,19 @@ class PowerSampler:
                 'watts_max': round(max(w), 0), 'power_cap_w': cap, 'nominal_sclk_mhz': NOMINAL_SCLK_MHZ, 'samples': len(f)}
 
 
+def kernel_source_sha16():
+    """First 16 hex digits of the sha256 over the kernel sources and the C header, in name order: what a profile was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'sradsgan_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'sradsgan_amd', 'csrc', '*.h'))
+                   + [os.path.join(ROOT, 'include', 'sradsgan_hip.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _time_launches(fn, iters=50):
     import torch
     for _ in range(5):
@@ -225,10 +238,17 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     w = torch.nn.Parameter(torch.randn(256, 64, 3, 3, device=device) * 0.02)
     b = torch.randn(256, device=device) * 0.01
     flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9
-    traffic = {}                        # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same mode)
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (same shape, same mode).  The file names the kernel sources
+    # it was measured on (`source_sha16`, tools/roofline_summary.py): counters of an older binary are refused, not reported.
+    traffic, traffic_note = {}, None
     if batch == PER_GPU_BATCH:
         try:
-            traffic = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json'))).get(math, {})
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'roofline_traffic.json')))
+            if tj.get('source_sha16') == kernel_source_sha16():
+                traffic = tj.get(math, {})
+            else:
+                traffic_note = ('profiles/roofline_traffic.json was measured on other kernel sources (%s, now %s): not reported'
+                                % (tj.get('source_sha16'), kernel_source_sha16()))
         except (OSError, ValueError):
             traffic = {}
     out = []
@@ -268,6 +288,8 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
                'traffic': traffic.get(key), 'flops_per_launch': flops, 'avg_launch_ms': round(ms, 4),
                'back_to_back_launch_ms': round(b2b, 4), 'isolated_launch_ms': round(iso, 4),
                'dtype_peak': peak_name}
+        if traffic_note:
+            rec['traffic_note'] = traffic_note
         # the same launch looped for ~1.2 s with the board's power and shader clock sampled: `peak` assumes the nominal
         # clock, the kernel runs at whatever clock the 1400 W cap leaves (extra keys, not part of frac)
         if not sustained:                                   # profiler runs: keep the per-dispatch statistics to the timed launches
@@ -315,27 +337,33 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     return out[0], out[1]
 
 
-def in_step_probe(step_fn, batch, kind, steps=4):
+def in_step_probe(step_fn, batch, kind, steps=4, armed=True):
     """What the step gets: `steps` more identical training steps with the library's timing probe armed on ONE conv geometry
     (RAB conv1, 3x3 64 -> 256 @ 54x54 at this batch: kind 1 = every fprop call, 3 = every weight-gradient call), i.e. HIP events
     around those launches on their own launch stream while the step's other streams share the chip (srhip_probe_*,
     include/sradsgan_hip.h).  Run AFTER the timed region so that the events are not part of `value`.  Returns
-    (average ms per convolution, calls, convolutions)."""
+    (average ms per convolution, calls, convolutions).
+    With more than one rank EVERY rank must call this (the steps carry the gradient exchange's collectives, so a rank that
+    skipped them would leave its peers' all-reduces unmatched); only the rank with `armed` arms and reads the probe."""
     import ctypes
     import torch
     from sradsgan_amd import _hip
     lib = _hip.lib()
     cap = 1024
-    _hip.check(lib.srhip_probe_config(kind, batch, LR_SIDE, LR_SIDE, 64, 256, cap), 'probe_config')
+    if armed:
+        _hip.check(lib.srhip_probe_config(kind, batch, LR_SIDE, LR_SIDE, 64, 256, cap), 'probe_config')
+    n = 0
     try:
         for _ in range(steps):
             step_fn()
         torch.cuda.synchronize()
-        ms = (ctypes.c_float * cap)()
-        units = (ctypes.c_int * cap)()
-        n = lib.srhip_probe_read(ms, units, cap)
+        if armed:
+            ms = (ctypes.c_float * cap)()
+            units = (ctypes.c_int * cap)()
+            n = lib.srhip_probe_read(ms, units, cap)
     finally:
-        lib.srhip_probe_config(0, 0, 0, 0, 0, 0, 0)
+        if armed:
+            lib.srhip_probe_config(0, 0, 0, 0, 0, 0, 0)
     if n <= 0:
         return None, 0, 0
     convs = sum(units[i] for i in range(n))
@@ -594,14 +622,20 @@ def cpu_baseline_subprocess(iters, timeout_s=240):
 
 
 def visible_gpu_count():
-    """GPUs this process could use, counted WITHOUT opening the GPU driver (the launcher parent must never touch HIP before
-    it spawns its ranks, and `torch.cuda.device_count()` falls back to hipGetDeviceCount when amdsmi is absent): KFD topology
-    nodes with a non-zero simd_count are the GPU agents; a *_VISIBLE_DEVICES list narrows them like the runtime would."""
+    """GPUs this process could use, counted WITHOUT opening the GPU driver in THIS process (the launcher parent must never touch
+    HIP before it spawns its ranks, and `torch.cuda.device_count()` falls back to hipGetDeviceCount when amdsmi is absent): KFD
+    topology nodes with a non-zero simd_count are the GPU agents; a *_VISIBLE_DEVICES list narrows them like the runtime would.
+    The sysfs count is an UPPER bound only (a cgroup may expose fewer render nodes than the host's topology lists; ranks then
+    fail at set_device and the supervisor reports it).  Where the topology directory is masked or absent the devices are counted
+    by a short-lived child process instead (the parent stays GPU-free)."""
     import glob
     n = 0
-    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    readable = False
+    for path in nodes:
         try:
             with open(path) as f:
+                readable = True
                 for line in f:
                     parts = line.split()
                     if len(parts) == 2 and parts[0] == 'simd_count' and int(parts[1]) > 0:
@@ -609,11 +643,151 @@ def visible_gpu_count():
                         break
         except (OSError, ValueError):
             pass
+    if not readable:
+        n = _child_gpu_count()
     for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
         v = os.environ.get(var)
         if v is not None:
             n = min(n, len([x for x in v.split(',') if x.strip() != '']))
     return n
+
+
+def _child_gpu_count(timeout_s=300):
+    """Device count as the HIP runtime of a CHILD process sees it (sysfs unavailable); 0 when that fails."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'], capture_output=True,
+                             text=True, timeout=timeout_s)
+        return max(0, int(out.stdout.strip().splitlines()[-1]))
+    except (subprocess.SubprocessError, OSError, ValueError, IndexError):
+        return 0
+
+
+def _touch(path):
+    with open(path, 'a'):
+        os.utime(path, None)
+
+
+class Heartbeat:
+    """Worker side of the per-rank supervisor: touches BENCH_HB_FILE (when set) so that the supervisor can tell a rank that is
+    working from one that sits in a collective its peers never joined."""
+
+    def __init__(self):
+        self.path = os.environ.get('BENCH_HB_FILE')
+
+    def __call__(self):
+        if self.path:
+            try:
+                _touch(self.path)
+            except OSError:
+                pass
+
+
+def supervise_rank(args, worker_cmd=None, coord_dir=None):
+    """One of these per rank whenever N > 1 (under torch.distributed.run as well as under self_launch): the process the launcher
+    started stays GPU-free (no torch import, nothing is exec'd over an initialised runtime) and runs the real rank as a CHILD.
+
+    Why: the driver's N > 1 run is the first time the overlapped gradient exchange (dp.GradSync.start: RCCL collectives enqueued
+    tens of milliseconds ahead of their inputs on a high-priority stream) meets real peers -- no box with two GPUs was ever
+    available to the builder.  If that attempt fails (a rank exits non-zero) or stalls (a rank's heartbeat stops), EVERY rank's
+    supervisor stops its worker and starts a FRESH one with SRHIP_DP_HOST_SYNC=1 (dp.py: nothing enqueued ahead of its inputs;
+    produce, exchange, consume serially -- costs the overlap, about 1 ms per step) on a new rendezvous port.  The JSON line says
+    which mode produced it (`exchange_mode`, `launch_attempt`).  Rank 0's stdout is held back until every rank of the attempt
+    has finished, so a failed attempt never leaves a line behind.
+
+    The supervisors agree through files in a directory all ranks derive alike (MASTER_PORT + the launcher's pid):
+    fail.<attempt> (any supervisor: this attempt is over), done.<attempt>.<rank>, port.<attempt> (rank 0: rendezvous port of
+    a retry), hb.<attempt>.<rank> (the worker's heartbeat)."""
+    import socket
+    import subprocess
+    import tempfile
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    port0 = os.environ.get('MASTER_PORT', '29533')
+    if coord_dir is None:
+        coord_dir = os.environ.get('BENCH_COORD_DIR') or os.path.join(tempfile.gettempdir(), 'srhip_bench_%s_%d' % (port0, os.getppid()))
+    os.makedirs(coord_dir, exist_ok=True)
+    first_hb_s = float(os.environ.get('BENCH_FIRST_HEARTBEAT_S', '420'))     # fresh box: the first `import torch` alone can take 2 min
+    stale_s = float(os.environ.get('BENCH_HEARTBEAT_STALE_S', '150'))
+    max_attempts = 1 if os.environ.get('BENCH_NO_RETRY') == '1' else 2
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] if worker_cmd is None else list(worker_cmd)
+    path = lambda name: os.path.join(coord_dir, name)
+    rc = 1
+    for attempt in range(1, max_attempts + 1):
+        env = dict(os.environ, BENCH_WORKER='1', BENCH_ATTEMPT=str(attempt), BENCH_HB_FILE=path('hb.%d.%d' % (attempt, rank)))
+        if attempt > 1:
+            env['SRHIP_DP_HOST_SYNC'] = '1'
+            env['TORCHELASTIC_USE_AGENT_STORE'] = 'False'    # the launcher's store still holds attempt 1's keys: rank 0 hosts a new one
+            if rank == 0:
+                sock = socket.socket()
+                sock.bind(('127.0.0.1', 0))
+                new_port = sock.getsockname()[1]
+                sock.close()
+                with open(path('port.%d.tmp' % attempt), 'w') as f:
+                    f.write(str(new_port))
+                os.replace(path('port.%d.tmp' % attempt), path('port.%d' % attempt))
+            t_wait = time.monotonic() + 60.0
+            while not os.path.exists(path('port.%d' % attempt)):
+                if time.monotonic() > t_wait:
+                    print('bench.py: rank %d never saw the retry port of attempt %d' % (rank, attempt), file=sys.stderr)
+                    return 1
+                time.sleep(0.05)
+            env['MASTER_PORT'] = open(path('port.%d' % attempt)).read().strip()
+            env['MASTER_ADDR'] = '127.0.0.1'
+        out_path = path('stdout.%d.%d' % (attempt, rank))
+        with open(out_path, 'w') as out_f:
+            proc = subprocess.Popen(cmd, env=env, stdout=out_f)
+        t_start = time.monotonic()
+        why = None
+        done_written = False
+        try:
+            while True:
+                if os.path.exists(path('fail.%d' % attempt)):
+                    why = why or 'a peer reported failure'
+                    break
+                code = proc.poll()
+                if code is not None and not done_written:
+                    if code != 0:
+                        why = 'worker exited with code %d' % code
+                        rc = code
+                        _touch(path('fail.%d' % attempt))
+                        break
+                    _touch(path('done.%d.%d' % (attempt, rank)))
+                    done_written = True
+                if done_written:
+                    if all(os.path.exists(path('done.%d.%d' % (attempt, r))) for r in range(world)):
+                        break
+                else:
+                    try:
+                        age = time.time() - os.stat(env['BENCH_HB_FILE']).st_mtime
+                        limit = stale_s
+                    except OSError:
+                        age, limit = time.monotonic() - t_start, first_hb_s
+                    if age > limit:
+                        why = 'no heartbeat from the worker for %.0f s' % age
+                        rc = 124
+                        _touch(path('fail.%d' % attempt))
+                        break
+                time.sleep(0.1)
+        finally:
+            if proc.poll() is None:
+                proc.terminate()                              # the exact child we started
+                try:
+                    proc.wait(timeout=10.0)
+                except subprocess.TimeoutExpired:
+                    proc.kill()
+                    proc.wait()
+        if why is None:                                       # every rank of this attempt finished
+            if rank == 0:
+                sys.stdout.write(open(out_path).read())
+                sys.stdout.flush()
+            return 0
+        print('bench.py: rank %d, attempt %d (%s exchange) ended: %s%s' % (
+            rank, attempt, 'host-synchronised' if attempt > 1 else 'overlapped', why,
+            '; retrying with SRHIP_DP_HOST_SYNC=1 in fresh processes' if attempt < max_attempts else ''), file=sys.stderr)
+        if rc == 0:
+            rc = 1
+    return rc
 
 
 def self_launch(args, script=None, argv=None, visible=None):
@@ -685,9 +859,6 @@ def main():
         return
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -695,6 +866,13 @@ def main():
         # a line with n_gpus != --gpus would void the scaling record: refuse instead of running a different job
         raise SystemExit('bench.py: WORLD_SIZE=%d but --gpus %d; run `python bench.py --gpus %d` (it starts the ranks itself) '
                          'or torch.distributed.run --nproc-per-node %d' % (world, args.gpus, args.gpus, args.gpus))
+    if args.gpus > 1 and os.environ.get('BENCH_WORKER') != '1' and args.workload == 'train' and not args.roofline_only:
+        sys.exit(supervise_rank(args))                        # this process stays GPU-free; the rank itself is its child
+    hb = Heartbeat()
+    hb()
+    import torch
+    import torch.distributed as dist
+    hb()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the HIP path')
     from sradsgan_amd import _hip
@@ -739,15 +917,22 @@ def main():
     alpha = torch.rand(B, 1, 1, 1, generator=gen).to(device)
 
     def barrier():
+        hb()
         if world > 1 or force_dist:
+            # drain this rank's own queues first: the gradient exchange has its own RCCL communicator (csrc/dp_rccl.hip), and a
+            # collective of torch's communicator must not be launched while one of the other is still parked behind an event
+            # (two communicators whose kernels start in different orders on different ranks is RCCL's classic deadlock)
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
+        hb()
 
     if os.environ.get('BENCH_MAIN_STREAM') in ('1', '2'):       # experiment: the step on a non-default (non-blocking) stream; 2: at high priority
         torch.cuda.set_stream(torch.cuda.Stream(priority=-1 if os.environ['BENCH_MAIN_STREAM'] == '2' else 0))
     trace = []
     for _ in range(max(0, args.spinup_steps)):                  # untimed, before the contract's W warm-up steps
         step(lr, hr, alpha)
+        hb()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = step(lr, hr, alpha)
@@ -801,6 +986,15 @@ def main():
                'ms_per_step': round(dt1 / args.steps * 1e3, 3), 'steps': args.steps,
                'step_frac_of_mfma_peak': round(world * B * args.steps / dt1 * GF_PER_IMG_ITER / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4)}
 
+    # The two roofline kernels INSIDE the step (three streams on a power-capped chip): 2 x 4 more steps after the timed region with
+    # the library's probe armed on rank 0.  EVERY rank runs these steps -- with N > 1 each step carries the RCCL all-reduces of the
+    # gradient exchange, and a rank that sat in the final barrier instead would leave rank 0's collectives unmatched for ever.
+    probes = {}
+    if not _use_graph(args) and B == PER_GPU_BATCH:
+        for key, kind in (('roofline', 1), ('roofline_wgrad', 3)):
+            probes[key] = (kind,) + tuple(in_step_probe(lambda: step(lr, hr, alpha), B, kind, armed=(rank == 0)))
+        barrier()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -821,24 +1015,26 @@ def main():
         line['power'] = sampler.summary()                       # board power / shader clock over the timed region (rank 0's GPU)
         if sync is not None:
             line['rccl_ranks'] = sync.rccl_ranks()             # size of the communicator the gradients really went through
+            if line['rccl_ranks'] != world:
+                raise SystemExit('bench.py: the gradients went through a communicator of %d ranks, the job has %d' % (line['rccl_ranks'], world))
             line['exchange'] = 'srhip_dp_allreduce_bucket on a dedicated HIP stream, G arena under the D step'
+            line['exchange_mode'] = ('host-synchronised (SRHIP_DP_HOST_SYNC=1: produce, exchange, consume serially)' if sync.host_sync
+                                     else 'overlapped (collectives enqueued ahead of their inputs, ordered by events)')
+            line['launch_attempt'] = int(os.environ.get('BENCH_ATTEMPT', '1'))
         if alt is not None:
             line['exact_fp32_mode'] = alt
         line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B, not args.no_sustained)
-        if not _use_graph(args) and B == PER_GPU_BATCH:
-            # the same two kernels INSIDE the step (three streams on a power-capped chip): isolated steady state above, this below
-            peak = MATH_PEAK[conv_math][0]
-            conv_flops = 2.0 * B * LR_SIDE * LR_SIDE * 256 * 64 * 9
-            for key, kind in (('roofline', 1), ('roofline_wgrad', 3)):
-                ms_conv, calls, convs = in_step_probe(lambda: step(lr, hr, alpha), B, kind)
-                if ms_conv:
-                    line[key]['in_step_avg_launch_ms'] = round(ms_conv * (convs / calls), 4)     # per CALL, like avg_launch_ms
-                    line[key]['in_step_ms_per_convolution'] = round(ms_conv, 4)
-                    line[key]['in_step_frac'] = round(conv_flops / (ms_conv * 1e-3) / 1e12 / peak, 4)
-                    line[key]['in_step_calls_timed'] = calls
-                    line[key]['in_step_note'] = ('HIP events around every %s call of this geometry on its launch stream during 4 extra training steps '
-                                                 'after the timed region (srhip_probe_*): the other two streams of the step share the chip'
-                                                 % ('fprop' if kind == 1 else 'weight-gradient'))
+        peak = MATH_PEAK[conv_math][0]
+        conv_flops = 2.0 * B * LR_SIDE * LR_SIDE * 256 * 64 * 9
+        for key, (kind, ms_conv, calls, convs) in probes.items():
+            if ms_conv:
+                line[key]['in_step_avg_launch_ms'] = round(ms_conv * (convs / calls), 4)     # per CALL, like avg_launch_ms
+                line[key]['in_step_ms_per_convolution'] = round(ms_conv, 4)
+                line[key]['in_step_frac'] = round(conv_flops / (ms_conv * 1e-3) / 1e12 / peak, 4)
+                line[key]['in_step_calls_timed'] = calls
+                line[key]['in_step_note'] = ('HIP events around every %s call of this geometry on its launch stream during 4 extra training steps '
+                                             'after the timed region (srhip_probe_*): the other two streams of the step share the chip'
+                                             % ('fprop' if kind == 1 else 'weight-gradient'))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
     if world > 1 or force_dist:

@@ -1,6 +1,7 @@
 """Generate tests/golden/*.npz by running the REFERENCE modules (run in the build container only).
 
     python oracle/make_golden.py            # needs /root/reference; never runs on the GPU box
+    python oracle/make_golden.py gabup_x8 gen_small_x8 ...   # only the named fixtures (the others stay as committed)
 
 The reference (Meng-333/SRADSGAN) ships no tests or golden vectors, so the
 vectors that pin the oracle are produced here by importing reference/SRADSGAN/model/sradsgan.py
@@ -88,7 +89,12 @@ def np32(t):
     return O.digest(t)
 
 
+ONLY = set(sys.argv[1:])                    # fixture names to (re)write; empty = all of them
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, **arrays)
@@ -134,10 +140,10 @@ def main():
                ['RG.1.conv2.weight', 'ca.fc2.weight', 'sa.conv1.weight', 'conv.bias'])
     x3 = O.det_fill('x3', (2, 3, 10, 12), 0.5, 0.5)
     run_module('msb', R.MSB(3, 64), x3, ['conv1.weight', 'conv2.0.weight', 'conv2.1.bias', 'conv.weight'])
-    for s in (2, 3, 4, 9):
+    for s in (2, 3, 4, 8, 9):                 # x8 = three tied x2 stages (sradsgan.py:388-392), x9 = two tied x3 stages
         run_module('gabup_x%d' % s, R.GAB_UP(upscale_factor=s), x64[:1, :, :6, :7] * 0.3,
                    ['upsampling.0.weight', 'upsampling.0.bias', 'conv.weight', 'ca.gamma', 'sa.gamma'])
-    for s in (2, 3, 4):
+    for s in (2, 3, 4, 8, 9):
         g = R.GeneratorResNet(R.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s)
         run_module('gen_small_x%d' % s, g, x3[:1],
                    ['conv1.0.weight', 'res_groups.0.RG.0.conv1.weight', 'res_groups.1.conv.weight',
@@ -232,6 +238,8 @@ def main():
             rec['D_after__' + k.replace('.', '__')] = np32(ds[k]).ravel()[:64]
         save(tag, **rec)
 
+    if ONLY and not ({'train_small', 'train_full'} & ONLY):
+        return
     ref_train('train_small', n_groups=2, n_blocks=1, batch=2, lr_side=8, scale=4, iters=2, thr=8)
     ref_train('train_full', n_groups=12, n_blocks=3, batch=2, lr_side=54, scale=4, iters=2, thr=8)
 

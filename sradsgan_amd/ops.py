@@ -85,6 +85,9 @@ def direct_param_grads(side_stream=None, group=1):
     try:
         yield
         flush_pending_wgrads()
+        if _state.pending:                             # before the restore below wipes the evidence
+            raise RuntimeError('direct_param_grads: %d grouped weight gradient(s) still waiting for a partner after the flush'
+                               % len(_state.pending))
     finally:
         _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held = prev
 

@@ -465,7 +465,6 @@ class TrainStep:
             out = self._compute(imgs_lr, imgs_hr, alpha)
         if side is not None:
             _join_side(torch.cuda.current_stream(), side)     # all weight gradients landed before the update
-        assert not ops._state.pending, 'weight gradients still waiting for a partner at the optimiser step'
         return out
 
     def _capture(self, imgs_lr, imgs_hr, alpha):

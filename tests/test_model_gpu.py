@@ -159,7 +159,7 @@ def test_msb(golden):
                  ['conv1.weight', 'conv2.0.weight', 'conv2.1.bias', 'conv.weight'])
 
 
-@pytest.mark.parametrize('s', [2, 3, 4, 9])
+@pytest.mark.parametrize('s', [2, 3, 4, 8, 9])
 def test_gab_up(golden, s):
     from sradsgan_amd import model as M
     _module_case(golden, 'gabup_x%d' % s, M.GAB_UP(upscale_factor=s), O.GAB_UP(upscale_factor=s),
@@ -167,7 +167,7 @@ def test_gab_up(golden, s):
                  ['upsampling.0.weight', 'upsampling.0.bias', 'conv.weight', 'ca.gamma', 'sa.gamma'])
 
 
-@pytest.mark.parametrize('s', [2, 3, 4])
+@pytest.mark.parametrize('s', [2, 3, 4, 8, 9])
 def test_generator_small(golden, s):
     from sradsgan_amd import model as M
     _module_case(golden, 'gen_small_x%d' % s,

@@ -81,13 +81,13 @@ def test_msb(golden):
                 ['conv1.weight', 'conv2.0.weight', 'conv2.1.bias', 'conv.weight'])
 
 
-@pytest.mark.parametrize('s', [2, 3, 4, 9])
+@pytest.mark.parametrize('s', [2, 3, 4, 8, 9])
 def test_gab_up(golden, s):
     _run_module(golden, 'gabup_x%d' % s, O.GAB_UP(upscale_factor=s), X64()[:1, :, :6, :7] * 0.3,
                 ['upsampling.0.weight', 'upsampling.0.bias', 'conv.weight', 'ca.gamma', 'sa.gamma'])
 
 
-@pytest.mark.parametrize('s', [2, 3, 4])
+@pytest.mark.parametrize('s', [2, 3, 4, 8, 9])
 def test_generator_small(golden, s):
     g = O.GeneratorResNet(O.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s)
     _run_module(golden, 'gen_small_x%d' % s, g, X3()[:1],

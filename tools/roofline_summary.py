@@ -47,6 +47,9 @@ for mode in ('fp32', 'bf16x3', 'half'):
             total += (fetch + write) * weight
         out[mode][key] = int(total)
 open(os.path.join(root, 'summary.txt'), 'w').write('\n'.join(lines) + '\n')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out['source_sha16'] = bench.kernel_source_sha16()      # bench.py refuses the file once the kernel sources have changed
 json.dump(out, open(os.path.join(root, 'roofline_traffic.json'), 'w'), indent=1)
 print('\n'.join(lines))
 print(json.dumps(out))
