@@ -21,7 +21,22 @@ def _close(got, want, tol=TOL, msg=''):
     assert err <= tol * scale, '%s: max abs err %.3e vs scale %.3e' % (msg, err, scale)
 
 
-def _module_case(golden, tag, hip_mod, ora_mod, x, grad_keys):
+def _close_but_for_flips(got, want, msg=''):
+    """Parameter gradients of the default split-bf16 arithmetic on the x8 / x9 generators (three / two tied up-sampling stages,
+    ~1e6 LeakyReLU inputs behind one weight tensor): a pre-activation within the arithmetic's ~5e-6 of zero takes the other slope
+    than in the oracle, which moves the gradients of the few weights behind that one element by a finite amount (tools/_x9diag.py:
+    0.7 % of the up-sampler's weight gradients, ONE bias element, 2.8e-3 of the tensor's scale; the same graph in exact-fp32 conv
+    arithmetic meets 1e-3 everywhere and is asserted right next to this).  Bar: 99 % of the elements within TOL, none beyond 1e-2."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = max(float(np.abs(want).max()), FLOOR)
+    err = np.abs(got - want)
+    frac = float((err > TOL * scale).mean())
+    assert frac <= 0.01 and float(err.max()) <= 1e-2 * scale, \
+        '%s: %.2f %% of the elements beyond %.0e, max abs err %.3e vs scale %.3e' % (msg, 100 * frac, TOL, float(err.max()), scale)
+
+
+def _module_case(golden, tag, hip_mod, ora_mod, x, grad_keys, flips=False):
+    close_grad = _close_but_for_flips if flips else _close
     g = golden(tag)
     O.det_init_(ora_mod, prefix=tag + '.')
     hip_mod.load_state_dict(ora_mod.state_dict(), strict=True)
@@ -48,8 +63,8 @@ def _module_case(golden, tag, hip_mod, ora_mod, x, grad_keys):
             err = float(hp[k].grad.cpu().abs().max())
             assert err <= TOL * scale, '%s: |roundoff| %.3e vs weight-gradient scale %.3e' % (k, err, scale)
             continue
-        _close(hp[k].grad.cpu(), op[k].grad, msg=k + ' vs oracle')
-        _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], msg=k + ' vs reference')
+        close_grad(hp[k].grad.cpu(), op[k].grad, msg=k + ' vs oracle')
+        close_grad(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], msg=k + ' vs reference')
 
 
 X64 = lambda: O.det_fill('x64', (2, 64, 10, 12), 1.0)
@@ -169,12 +184,20 @@ def test_gab_up(golden, s):
 
 @pytest.mark.parametrize('s', [2, 3, 4, 8, 9])
 def test_generator_small(golden, s):
-    from sradsgan_amd import model as M
-    _module_case(golden, 'gen_small_x%d' % s,
-                 M.GeneratorResNet(M.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s),
-                 O.GeneratorResNet(O.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s), X3()[:1],
-                 ['conv1.0.weight', 'res_groups.0.RG.0.conv1.weight', 'res_groups.1.conv.weight',
-                  'GAB_UP.upsampling.0.weight', 'MSB.conv.weight', 'conv3.0.bias'])
+    from sradsgan_amd import model as M, ops
+    keys = ['conv1.0.weight', 'res_groups.0.RG.0.conv1.weight', 'res_groups.1.conv.weight',
+            'GAB_UP.upsampling.0.weight', 'MSB.conv.weight', 'conv3.0.bias']
+    mk = lambda: (M.GeneratorResNet(M.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s),
+                  O.GeneratorResNet(O.ResGroup, n_residual_blocks=2, n_basic_blocks=1, upscale_factor=s))
+    if s >= 8:
+        # x8 / x9 (reference-generated vectors since round 5): the graph in exact-fp32 conv arithmetic meets the 1e-3 bar on every
+        # tensor (kernels and wiring, tied stages included); the default arithmetic then only has to be right up to LeakyReLU flips
+        with ops.conv_math('fp32'):
+            _module_case(golden, 'gen_small_x%d' % s, *mk(), X3()[:1], keys)
+        if ops.get_conv_math() != 'fp32':
+            _module_case(golden, 'gen_small_x%d' % s, *mk(), X3()[:1], keys, flips=True)
+        return
+    _module_case(golden, 'gen_small_x%d' % s, *mk(), X3()[:1], keys)
 
 
 def test_state_dict_keys_match_reference_contract():
