@@ -160,6 +160,30 @@ int srhip_conv2d_wgrad_multi_ok(int n, int h, int w, int cin, int cout, int kh, 
 int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const* dy, float* const* dw, float* const* db,
                              int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
                              int kh, int kw, int stride, int pad, int ldx, int ldy, void* stream);
+/* ---- ABI 9: padded split-bf16 planes ("pp") and the weight gradient as a flat GEMM over them (csrc/conv_wgrad_flat.hip) -------- *
+ * Replaces nothing new in the reference: it is the autograd of the RAB convs (sradsgan.py:222-223, 250-252) like
+ * srhip_conv2d_wgrad; what changes is the FORMAT the two 256-channel tensors inside a RAB (t = LeakyReLU(conv1 x) and its
+ * gradient) are kept in between the block's own kernels.
+ * pp of an NHWC tensor [N,H,W,C] (C % 8 == 0): 2 bf16 planes (hi = bf16(v), lo = bf16(v - hi)) of
+ * srhip_pp_plane_pixels(n,h,w) pixel rows of C channels each: srhip_pp_guard(w) zero rows, then pixel (n,y,x) at row
+ * (n*(H+1) + y)*(W+1) + x -- one zero pixel behind every image row, one zero row behind every image --, then a zero tail.
+ * The PAD / GUARD / TAIL ROWS MUST BE ZERO and no entry point ever writes them: allocate the buffer zeroed once and reuse it.
+ * srhip_pp_from_f32 / srhip_pp_to_f32 convert (valid pixels only; to_f32 returns hi + lo).
+ * srhip_conv2d_wgrad_pp: nprob (1..4) weight gradients of ONE 3x3 stride-1 pad-1 shape in one launch, split-bf16 arithmetic.
+ * x_pp / dy_pp say which operands are pp (the other is fp32 NHWC with row stride ldf); srhip_conv2d_wgrad_pp_ok returns the served
+ * combinations as a bit mask: 1 = x fp32 + dy pp (Cin % 64 == 0, Cout >= 128), 2 = x pp + dy fp32 (Cout == 64, Cin % 128 == 0),
+ * 4 = both pp (Cin % 64 == 0 and Cout >= 256, or Cout == 64 and Cin % 256 == 0: the 8-wave kernel, one block per CU).
+ * dw[i] (OIHW) and db[i] (optional) written or accumulated into; deterministic two-pass split-K as srhip_conv2d_wgrad. */
+int srhip_pp_guard(int w);
+long srhip_pp_plane_pixels(int n, int h, int w);
+int srhip_pp_from_f32(const float* x_nhwc, void* pp, int n, int h, int w, int c, int ldx, void* stream);
+int srhip_pp_to_f32(const void* pp, float* x_nhwc, int n, int h, int w, int c, int ldx, void* stream);
+int srhip_conv2d_wgrad_pp_ok(int n, int h, int w, int cin, int cout);
+size_t srhip_conv2d_wgrad_pp_workspace(int nprob, int x_pp, int dy_pp, int n, int h, int w, int cin, int cout);
+int srhip_conv2d_wgrad_pp(int nprob, const void* const* x, const void* const* dy, int x_pp, int dy_pp, float* const* dw, float* const* db,
+                          int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int ldf,
+                          void* stream);
+
 /* The same for a conv with a fused LeakyReLU (sradsgan.py:476: D's 3 -> 64 head conv), from the gradient at the ACTIVATED
  * output: dy * (y > 0 ? 1 : slope) is formed while dy is read, so no lrelu-backward pass is needed when only the weight and
  * bias gradients of the layer are wanted.  srhip_conv2d_wgrad_act_ok says whether the shape is served (3-channel 3x3

@@ -36,6 +36,13 @@ SIGNATURES = {
     'srhip_conv2d_wgrad_can_accumulate': (_i, [_i] * 4),
     'srhip_conv2d_wgrad_multi_ok': (_i, [_i] * 9),
     'srhip_conv2d_wgrad_multi': (_i, [_i] + [_vp] * 4 + [_i, _vp, _sz] + [_i] * 11 + [_vp]),
+    'srhip_pp_guard': (_i, [_i]),
+    'srhip_pp_plane_pixels': (_l, [_i] * 3),
+    'srhip_pp_from_f32': (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
+    'srhip_pp_to_f32': (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
+    'srhip_conv2d_wgrad_pp_ok': (_i, [_i] * 5),
+    'srhip_conv2d_wgrad_pp_workspace': (_sz, [_i] * 8),
+    'srhip_conv2d_wgrad_pp': (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz] + [_i] * 6 + [_vp]),
     'srhip_conv2d_wgrad_act_ok': (_i, [_i] * 9),
     'srhip_conv2d_wgrad_act': (_i, [_vp] * 3 + [_f] + [_vp] * 3 + [_sz] + [_i] * 11 + [_vp]),
     'srhip_conv2d_wgrad': (_i, [_vp] * 6 + [_i, _vp, _sz] + [_i] * 11 + [_vp]),

@@ -182,6 +182,14 @@ int srhip_debug_set(int key, int value) {
     g_pers_small = value;
     return SRHIP_OK;
   }
+  if (key == 12) {
+    g_flat_blocks = value > 0 ? value : 768;
+    return SRHIP_OK;
+  }
+  if (key == 13) {
+    g_flat_abl = value;
+    return SRHIP_OK;
+  }
   return SRHIP_ERR_ARG;
 }
 
@@ -361,6 +369,37 @@ int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* cons
   const int pi = pr ? probe_begin(stream) : 0;
   const int rc = fast_conv2d_wgrad_multi(nprob, x, dy, dw, db, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, kh, kw, stride, pad,
                                          ldx, ldy, as_stream(stream));
+  if (pr) probe_end(pi, stream, nprob);
+  return rc;
+}
+
+/* ---- ABI 9: padded split-bf16 planes and the flat weight gradient on them (conv_wgrad_flat.hip) ---- */
+int srhip_pp_guard(int w) { return pp_guard(w); }
+long srhip_pp_plane_pixels(int n, int h, int w) { return (n > 0 && h > 0 && w > 0) ? pp_plane_pixels(n, h, w) : 0; }
+int srhip_pp_from_f32(const float* x, void* pp, int n, int h, int w, int c, int ldx, void* stream) {
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && ldx >= c, "pp_from_f32: bad geometry");
+  return pp_from_f32(x, pp, n, h, w, c, ldx, stream);
+}
+int srhip_pp_to_f32(const void* pp, float* x, int n, int h, int w, int c, int ldx, void* stream) {
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && ldx >= c, "pp_to_f32: bad geometry");
+  return pp_to_f32(pp, x, n, h, w, c, ldx, stream);
+}
+int srhip_conv2d_wgrad_pp_ok(int n, int h, int w, int cin, int cout) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+  return flat_wgrad_ok(n, h, w, cin, cout);
+}
+size_t srhip_conv2d_wgrad_pp_workspace(int nprob, int x_pp, int dy_pp, int n, int h, int w, int cin, int cout) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+  return flat_wgrad_workspace(nprob, x_pp, dy_pp, n, h, w, cin, cout);
+}
+int srhip_conv2d_wgrad_pp(int nprob, const void* const* x, const void* const* dy, int x_pp, int dy_pp, float* const* dw, float* const* db,
+                          int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int ldf,
+                          void* stream) {
+  SRHIP_REQUIRE(x && dy && dw, "conv2d_wgrad_pp: null pointer table");
+  SRHIP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_wgrad_pp: bad geometry");
+  const bool pr = probe_hit(3, n, h, w, cin, cout);
+  const int pi = pr ? probe_begin(stream) : 0;
+  const int rc = flat_wgrad(nprob, x, dy, x_pp, dy_pp, dw, db, accumulate, workspace, workspace_bytes, n, h, w, cin, cout, ldf, stream);
   if (pr) probe_end(pi, stream, nprob);
   return rc;
 }

@@ -2239,7 +2239,7 @@ struct ReduceBatch {
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 template <int SUB>
 __global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce4_kernel(ReduceBatch rb, int nsplit, int cout, int cin, int khkw,
-                                                                      int ktot, int accumulate) {
+                                                                      int ktot, int accumulate, int nbias) {   // nbias: rows of bias_partial (= nsplit but for conv_wgrad_flat.hip's flat8 kernel)
   __shared__ float4 red[64 * SUB];
   const int prob = blockIdx.y;
   const float* __restrict__ partial = rb.partial[prob];
@@ -2261,7 +2261,7 @@ __global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce4_kernel(ReduceBatc
     for (; i < nsplit; i += SUB) s0 = add4(s0, *reinterpret_cast<const float4*>(partial + (size_t)i * total + e));
   } else if (db != nullptr && e < total + cout) {
     const int co = e - total;
-    for (int i = sub; i < nsplit; i += SUB) s0 = add4(s0, *reinterpret_cast<const float4*>(bias_partial + (size_t)i * cout + co));
+    for (int i = sub; i < nbias; i += SUB) s0 = add4(s0, *reinterpret_cast<const float4*>(bias_partial + (size_t)i * cout + co));
   }
   red[threadIdx.x] = add4(add4(s0, s1), add4(s2, s3));
   __syncthreads();
@@ -2287,7 +2287,8 @@ __global__ __launch_bounds__(64 * SUB) void fast_wgrad_reduce4_kernel(ReduceBatc
 }
 // one launch for nprob problems of one shape; false: the caller takes the scalar kernel (shapes / pointers the 16-byte form cannot serve)
 static bool launch_reduce4(int nprob, const float* const* partial, const float* const* bias_partial, float* const* dw, float* const* db,
-                           int nsplit, int cout, int cin, int khkw, int ktot, int accumulate, hipStream_t st) {
+                           int nsplit, int cout, int cin, int khkw, int ktot, int accumulate, hipStream_t st, int nbias = -1) {
+  if (nbias < 0) nbias = nsplit;
   extern int g_wgrad_cfg;
   if (g_wgrad_cfg == 8 || nprob < 1 || nprob > 4 || ktot % 4 != 0 || cout % 4 != 0 || cin % 4 != 0) return false;
   ReduceBatch rb;
@@ -2303,10 +2304,15 @@ static bool launch_reduce4(int nprob, const float* const* partial, const float* 
   }
   const long total = (long)cout * ktot + (anydb ? cout : 0);
   if (nsplit >= 64)
-    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<16>, dim3(cdiv(total, 256), nprob), dim3(1024), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate);
+    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<16>, dim3(cdiv(total, 256), nprob), dim3(1024), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate, nbias);
   else
-    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<4>, dim3(cdiv(total, 256), nprob), dim3(256), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate);
+    hipLaunchKernelGGL(fast_wgrad_reduce4_kernel<4>, dim3(cdiv(total, 256), nprob), dim3(256), 0, st, rb, nsplit, cout, cin, khkw, ktot, accumulate, nbias);
   return true;
+}
+
+bool launch_reduce4_shared(int nprob, const float* const* partial, const float* const* bias_partial, float* const* dw, float* const* db,
+                           int nsplit, int cout, int cin, int khkw, int ktot, int accumulate, hipStream_t st, int nbias) {
+  return launch_reduce4(nprob, partial, bias_partial, dw, db, nsplit, cout, cin, khkw, ktot, accumulate, st, nbias);   // conv_wgrad_flat.hip
 }
 
 // ================================================================================================ //

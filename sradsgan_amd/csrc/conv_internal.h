@@ -79,6 +79,18 @@ int fast_conv2d_wgrad_multi(int nprob, const float* const* x, const float* const
                             int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout,
                             int kh, int kw, int stride, int pad, int ldx, int ldy, hipStream_t st);
 
+// ---- padded split-bf16 planes and the flat weight gradient on them (conv_wgrad_flat.hip, round 5) ---- //
+int pp_guard(int w);
+long pp_plane_pixels(int n, int h, int w);
+int pp_from_f32(const float* x, void* pp, int n, int h, int w, int c, int ldx, void* stream);
+int pp_to_f32(const void* pp, float* x, int n, int h, int w, int c, int ldx, void* stream);
+int flat_wgrad_ok(int n, int h, int w, int cin, int cout);      // bit mask of served operand formats: 1 x fp32 + dy planes, 2 x planes + dy fp32, 4 both planes
+size_t flat_wgrad_workspace(int nprob, int x_pp, int dy_pp, int n, int h, int w, int cin, int cout);
+int flat_wgrad(int nprob, const void* const* x, const void* const* dy, int x_pp, int dy_pp, float* const* dw, float* const* db, int accumulate,
+               void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int ldf, void* stream);
+extern int g_flat_blocks;
+extern int g_flat_abl;
+
 // column sums (elementwise.hip), used for the bias gradient on the generic path
 size_t colsum_workspace_bytes(long rows, int c);
 int colsum_launch(const float* dy, float* db, void* workspace, long rows, int c, int ld, hipStream_t st);

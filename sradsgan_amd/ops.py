@@ -491,6 +491,77 @@ def conv2d_wgrad_multi_raw(items, on_stream=None):
                                            stride, pad, cin, cout, st), 'conv2d_wgrad_multi')
 
 
+# ---- padded split-bf16 planes (include/sradsgan_hip.h, ABI 9) ---------------------------------------------------------- #
+class PP:
+    """Padded planes of an NHWC tensor [n, c, h, w]: `buf` = bf16 [2, srhip_pp_plane_pixels(n, h, w), c] (hi | lo), pad / guard /
+    tail rows zero.  The kernels never write those rows, so a buffer is zeroed ONCE (pp_empty) and can then be reused for any
+    tensor of the same geometry."""
+    __slots__ = ('buf', 'n', 'c', 'h', 'w')
+
+    def __init__(self, buf, n, c, h, w):
+        self.buf, self.n, self.c, self.h, self.w = buf, n, c, h, w
+
+    @property
+    def shape(self):
+        return (self.n, self.c, self.h, self.w)
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+
+
+def pp_empty(n, c, h, w, device):
+    px = _hip.lib().srhip_pp_plane_pixels(n, h, w)
+    return PP(torch.zeros(2, px, c, device=device, dtype=torch.bfloat16), n, c, h, w)
+
+
+def pp_from_f32(x, out=None):
+    """fp32 [n, c, h, w] (NHWC memory) -> padded planes (a stand-alone pass: tests, the bench's operand set-up)."""
+    _require_gpu(x, 'pp_from_f32')
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    pp = out if out is not None else pp_empty(n, c, h, w, x.device)
+    _hip.check(_hip.lib().srhip_pp_from_f32(_p(x), _p(pp.buf), n, h, w, c, c, _stream()), 'pp_from_f32')
+    return pp
+
+
+def pp_to_f32(pp):
+    out = torch.empty(pp.n, pp.c, pp.h, pp.w, device=pp.buf.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    _hip.check(_hip.lib().srhip_pp_to_f32(_p(pp.buf), _p(out), pp.n, pp.h, pp.w, pp.c, pp.c, _stream()), 'pp_to_f32')
+    return out
+
+
+def conv2d_wgrad_pp_raw(items, accumulate=True, on_stream=None):
+    """items: [(x, dy, dw_buf, db_buf or None)] -- 1..4 weight gradients of ONE 3x3 stride-1 pad-1 shape by one launch of the flat
+    kernels (srhip_conv2d_wgrad_pp): x and / or dy are PP objects (padded planes), an operand that is not is fp32 NHWC."""
+    x0, dy0, dw0, _ = items[0]
+    cout, cin = dw0.shape[0], dw0.shape[1]
+    n, _, h, wd = x0.shape
+    lib = _hip.lib()
+    xpp, ypp = int(isinstance(x0, PP)), int(isinstance(dy0, PP))
+    mask = lib.srhip_conv2d_wgrad_pp_ok(n, h, wd, cin, cout)
+    want = 4 if (xpp and ypp) else 1 if ypp else 2 if xpp else 0
+    if not (mask & want):
+        raise RuntimeError('conv2d_wgrad_pp: shape %s -> %d not served with these operand formats (served mask %d)' % (tuple(x0.shape), cout, mask))
+    k = len(items)
+    tab = ctypes.c_void_p * k
+    xs = tab(*[it[0].data_ptr() for it in items])
+    dys = tab(*[it[1].data_ptr() for it in items])
+    dws = tab(*[it[2].data_ptr() for it in items])
+    dbs = tab(*[(it[3].data_ptr() if it[3] is not None else None) for it in items])
+    nbytes = lib.srhip_conv2d_wgrad_pp_workspace(k, xpp, ypp, n, h, wd, cin, cout)
+    if on_stream is not None:
+        ws = _side_workspace(nbytes, dw0.device, on_stream)
+        st = ctypes.c_void_p(on_stream.cuda_stream)
+    else:
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, device=dw0.device, dtype=torch.float32)
+        st = _stream()
+    _hip.check(lib.srhip_conv2d_wgrad_pp(k, xs, dys, xpp, ypp, dws, dbs, 1 if accumulate else 0, _p(ws), ws.numel() * 4, n, h, wd, cin, cout,
+                                        cout if xpp else cin, st), 'conv2d_wgrad_pp')
+
+
 _WGRAD_DEFER = os.environ.get('SRHIP_WGRAD_DEFER', '0') == '1'     # experiment: hold every groupable weight gradient until a flush point
 _WGRAD_FLUSH_GROUP = int(os.environ.get('SRHIP_WGRAD_FLUSH_GROUP', '0'))   # convolutions per launch at a flush (0: the step's group size)
 
