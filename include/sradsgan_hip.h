@@ -175,6 +175,18 @@ int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* cons
  * 4 = both pp (Cin % 64 == 0 and Cout >= 256, or Cout == 64 and Cin % 256 == 0: the 8-wave kernel, one block per CU).
  * dw[i] (OIHW) and db[i] (optional) written or accumulated into; deterministic two-pass split-K as srhip_conv2d_wgrad. */
 int srhip_pp_guard(int w);
+/* 3x3 stride-1 pad-1 conv forward / data gradient with padded-plane operands (split-bf16 arithmetic; the persistent patch kernel,
+ * csrc/conv_patch_pers.hip): x_pp / y_pp (dy_pp / dx_pp) say which side is pp, the other is DENSE fp32 NHWC (row stride = channels).
+ * A pp source skips the kernel's in-place split; a pp destination gets the epilogue's rows as hi | lo stores.  Replaces the same
+ * nn.Conv2d call sites as srhip_conv2d_fwd / _dgrad inside the RAB (sradsgan.py:222-223, 250-252).
+ * fwd: flags = SRHIP_EPI_BIAS | SRHIP_EPI_LRELU subset; pool != NULL (fp32 destination of 64 channels): also the CLAM pooling
+ * partials as srhip_conv2d_fwd_pool.  dgrad: residual (fp32 destination only) is added; actmask (pp destination only) = the PP of
+ * the LeakyReLU output that fed the forward conv: dx is multiplied by the activation's derivative. */
+int srhip_conv2d_pp_ok(int n, int h, int w, int cin, int cout);
+int srhip_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const float* bias, void* y, int y_pp, float* pool, size_t pool_sec_bytes,
+                        int* nseg_out, int n, int h, int w, int cin, int cout, float slope, int flags, void* stream);
+int srhip_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,
+                          float slope, int n, int h, int w, int cin, int cout, void* stream);
 long srhip_pp_plane_pixels(int n, int h, int w);
 int srhip_pp_from_f32(const float* x_nhwc, void* pp, int n, int h, int w, int c, int ldx, void* stream);
 int srhip_pp_to_f32(const void* pp, float* x_nhwc, int n, int h, int w, int c, int ldx, void* stream);

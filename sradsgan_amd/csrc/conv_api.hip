@@ -388,6 +388,59 @@ int srhip_conv2d_wgrad_pp_ok(int n, int h, int w, int cin, int cout) {
   if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
   return flat_wgrad_ok(n, h, w, cin, cout);
 }
+int srhip_conv2d_pp_ok(int n, int h, int w, int cin, int cout) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || g_conv_math != 1) return 0;
+  if (cin % 32 != 0 || cout % 8 != 0 || cout < 64 || cin < 32) return 0;
+  const long px = pp_plane_pixels(n, h, w);
+  return px * (cin > cout ? cin : cout) * 4L < (1L << 31) ? 1 : 0;
+}
+int srhip_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const float* bias, void* y, int y_pp, float* pool, size_t pool_sec_bytes,
+                        int* nseg_out, int n, int h, int w, int cin, int cout, float slope, int flags, void* stream) {
+  SRHIP_REQUIRE(x && packed && y && (x_pp || y_pp), "conv2d_fwd_pp: null tensor / no padded-plane operand");
+  SRHIP_REQUIRE(srhip_conv2d_pp_ok(n, h, w, cin, cout), "conv2d_fwd_pp: shape / arithmetic mode not served (srhip_conv2d_pp_ok)");
+  SRHIP_REQUIRE((flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) == 0 && (!(flags & SRHIP_EPI_BIAS) || bias), "conv2d_fwd_pp: bias / LeakyReLU epilogues only");
+  SRHIP_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)packed) & 15) == 0, "conv2d_fwd_pp: 16-byte aligned tensors");
+  const bool want_pool = pool != nullptr;
+  if (want_pool) {
+    SRHIP_REQUIRE(nseg_out && !y_pp && cout == 64 && !(flags & SRHIP_EPI_LRELU), "conv2d_fwd_pp: pooling partials: fp32 destination of 64 channels, plain / bias epilogue");
+    SRHIP_REQUIRE(pool_sec_bytes % 16 == 0 && pool_sec_bytes < (1u << 30) && (((uintptr_t)pool) & 15) == 0 &&
+                      pool_sec_bytes >= (size_t)n * POOL_MAXSEG * 64 * sizeof(float),
+                  "conv2d_fwd_pp: three 16-byte aligned sections of n * max_segments * 64 floats");
+    g_pool_req.out = pool;
+    g_pool_req.sec_bytes = (unsigned)pool_sec_bytes;
+    g_pool_req.served_nseg = 0;
+  }
+  const bool pr = probe_hit(1, n, h, w, cin, cout);
+  const int pi = pr ? probe_begin(stream) : 0;
+  const int rc = fast_conv2d_fwd_pp(x, x_pp, packed, bias, y, y_pp, n, h, w, cin, cout, cin, cout, slope, flags, as_stream(stream));
+  if (pr) probe_end(pi, stream);
+  if (want_pool) {
+    const int served = g_pool_req.served_nseg;
+    g_pool_req.out = nullptr;
+    g_pool_req.served_nseg = 0;
+    if (rc != SRHIP_OK) return rc;
+    if (served > 0) {
+      *nseg_out = served;
+      return SRHIP_OK;
+    }
+    *nseg_out = srhip_clam_pool_segments();
+    return srhip_clam_pool_partial(static_cast<const float*>(y), pool, pool_sec_bytes, n, h, w, cout, stream);
+  }
+  return rc;
+}
+int srhip_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,
+                          float slope, int n, int h, int w, int cin, int cout, void* stream) {
+  SRHIP_REQUIRE(dy && packed && dx && (dy_pp || dx_pp), "conv2d_dgrad_pp: null tensor / no padded-plane operand");
+  SRHIP_REQUIRE(srhip_conv2d_pp_ok(n, h, w, cout, cin), "conv2d_dgrad_pp: shape / arithmetic mode not served (srhip_conv2d_pp_ok of the transposed conv)");
+  SRHIP_REQUIRE(!(residual && dx_pp), "conv2d_dgrad_pp: a residual needs an fp32 destination");
+  SRHIP_REQUIRE(!actmask || dx_pp, "conv2d_dgrad_pp: an activation mask (padded planes of the producer's output) needs a padded-plane destination");
+  SRHIP_REQUIRE((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)packed | (uintptr_t)residual | (uintptr_t)actmask) & 15) == 0, "conv2d_dgrad_pp: 16-byte aligned tensors");
+  const bool pr = probe_hit(2, n, h, w, cin, cout);
+  const int pi = pr ? probe_begin(stream) : 0;
+  const int rc = fast_conv2d_dgrad_pp(dy, dy_pp, packed, dx, dx_pp, residual, actmask, slope, n, h, w, cin, cout, cout, cin, cin, as_stream(stream));
+  if (pr) probe_end(pi, stream);
+  return rc;
+}
 size_t srhip_conv2d_wgrad_pp_workspace(int nprob, int x_pp, int dy_pp, int n, int h, int w, int cin, int cout) {
   if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
   return flat_wgrad_workspace(nprob, x_pp, dy_pp, n, h, w, cin, cout);

@@ -21,6 +21,10 @@ struct FastGeom {
   float slope;
   int flags, accumulate, dst_identity;
   unsigned src_bytes, w_bytes;
+  // padded split-bf16 planes (conv_wgrad_flat.hip) as source / destination of the persistent patch kernel (round 5): the tensor is
+  // [2 planes][guard + N (H+1) (W+1) + tail][channels] bf16; Hs / Ws (Hd / Wd) stay the LOGICAL image size
+  int src_pp = 0, dst_pp = 0, src_guard = 0, dst_guard = 0;
+  unsigned src_plane_bytes = 0, dst_plane_bytes = 0;
 };
 
 __device__ inline float4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -155,6 +159,6 @@ struct PoolRequest {
 extern thread_local PoolRequest g_pool_req;
 int launch_patch_pers(const float* src, const float* wt, const float* bias, const float* residual, const float* actmask,
                       float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
-                      hipStream_t st);
+                      hipStream_t st);     // g.src_pp / g.dst_pp: src / dst (and, with dst_pp, actmask) point at padded planes
 
 }  // namespace srhip

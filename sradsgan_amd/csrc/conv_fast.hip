@@ -2505,7 +2505,7 @@ int g_fast_cfg = 0;
 
 // Patch shape for conv_patch_kernel: PH x PW output pixels per block (<= 128), halo patch <= 192 rows = 12 DMA pieces; picks the
 // shape that wastes the fewest of the 128 GEMM rows over the whole image (halo patch <= 192 rows = 12 DMA pieces).  Only stride-1 3x3 geometries.
-static bool plan_patch(const FastGeom& g, PatchGeom* pg) {
+static bool plan_patch(const FastGeom& g, PatchGeom* pg, double min_eff = 0.70) {
   if (g.TH != 3 || g.TW != 3 || g.ss != 1 || g.dsd != 1 || g.ph != 0 || g.pw != 0) return false;
   if ((g.dhs != 1 && g.dhs != -1) || (g.dws != 1 && g.dws != -1)) return false;
   if (g.Hd != g.OH || g.Wd != g.OW) return false;
@@ -2523,7 +2523,7 @@ static bool plan_patch(const FastGeom& g, PatchGeom* pg) {
       pg->PH = ph; pg->PW = pw;
     }
   }
-  if (best < 0.70) return false;
+  if (best < min_eff || best <= 0.0) return false;
   pg->tiles_h = cdiv(g.OH, pg->PH);
   pg->tiles_w = cdiv(g.OW, pg->PW);
   pg->PWP = pg->PW + 2;
@@ -2566,6 +2566,20 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
                     const float* rowscale, const float* chanscale, const float* actmask, float* dst, const FastGeom& g,
                     hipStream_t st) {
   if (g.M <= 0) return SRHIP_OK;
+  if (g.src_pp || g.dst_pp) {                             // padded-plane operands: the persistent patch kernel or nothing
+    PatchGeom pg;
+    const int ef = g.flags & 0x3f;
+    if (g_conv_math == 1 && g.K >= 64 && g.K % 8 == 0 && g.C % 32 == 0 && !(ef & (SRHIP_EPI_CHANSCALE | SRHIP_EPI_ROWSCALE)) && !g.accumulate &&
+        plan_patch(g, &pg, 0.0)) {                        // (any patch efficiency: the planes have no other kernel)
+      const int nbm = g.N * pg.tiles_h * pg.tiles_w;
+      const bool wide = g.K >= 128;
+      const int nbn = cdiv(g.K, wide ? 128 : 64);
+      const int rc = launch_patch_pers(src, wt, bias, residual, actmask, dst, g, pg, nbm, nbn, wide, 0, ef, st);
+      if (rc >= 0) return rc;
+    }
+    set_error("conv2d (padded planes): shape / arithmetic mode not served by the persistent patch kernel");
+    return SRHIP_ERR_ARG;
+  }
 #define SRHIP_LF(BM_, BN_, WM_, WN_, BK_) \
   return launch_fast<BM_, BN_, WM_, WN_, BK_>(src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, st)
   // <= 4 destination channels, stride-1 3x3, big image: exact-fp32 VALU kernel (both arithmetic modes; cfg 22 turns it off)
@@ -2769,6 +2783,72 @@ int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, cons
   SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.src_bytes), "conv2d_fwd: source tensor >= 2 GiB");
   g.w_bytes = (unsigned)((long)cout * g.ldw * 4);
   return run_fast(x, packed, bias, residual, rowscale, chanscale, nullptr, y, g, st);
+}
+
+// 3x3 stride-1 pad-1 forward / data gradient with padded-plane operands (src_pp / dst_pp; with dst_pp an activation mask is pp too)
+int fast_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const float* bias, void* y, int y_pp, int n, int h, int w, int cin,
+                       int cout, int ldx, int ldy, float slope, int flags, hipStream_t st) {
+  FastGeom g;
+  g.N = n; g.Hs = h; g.Ws = w; g.C = cin; g.lds = x_pp ? cin : ldx;
+  g.OH = h; g.OW = w;
+  const long M = (long)n * h * w;
+  SRHIP_REQUIRE(M < (1L << 31), "conv2d_fwd_pp: pixel count overflows int32");
+  g.M = (int)M; g.ss = 1;
+  g.TH = 3; g.TW = 3; g.dh0 = -1; g.dhs = 1; g.dw0 = -1; g.dws = 1;
+  g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1; g.KW = 3;
+  g.Hd = h; g.Wd = w; g.dsd = 1; g.ph = 0; g.pw = 0; g.ldd = y_pp ? cout : ldy; g.K = cout;
+  g.ldw = 9 * cin; g.ldr = 0; g.slope = slope; g.flags = flags; g.accumulate = 0; g.dst_identity = 1;
+  const long ppx = pp_plane_pixels(n, h, w);
+  g.src_pp = x_pp; g.dst_pp = y_pp;
+  g.src_guard = g.dst_guard = pp_guard(w);
+  if (x_pp) {
+    SRHIP_REQUIRE(ppx * cin * 4L < (1L << 31), "conv2d_fwd_pp: source planes >= 2 GiB");
+    g.src_plane_bytes = (unsigned)(ppx * cin * 2L);
+    g.src_bytes = 2u * g.src_plane_bytes;
+  } else {
+    SRHIP_REQUIRE(bytes_ok(M, ldx, cin, &g.src_bytes), "conv2d_fwd_pp: source tensor >= 2 GiB");
+  }
+  if (y_pp) {
+    SRHIP_REQUIRE(ppx * cout * 4L < (1L << 31), "conv2d_fwd_pp: destination planes >= 2 GiB");
+    g.dst_plane_bytes = (unsigned)(ppx * cout * 2L);
+  }
+  g.w_bytes = (unsigned)((long)cout * g.ldw * 4);
+  return run_fast(static_cast<const float*>(x), packed, bias, nullptr, nullptr, nullptr, nullptr, static_cast<float*>(y), g, st);
+}
+
+int fast_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,
+                         float slope, int n, int h, int w, int cin, int cout, int ldy, int ldx, int ldr, hipStream_t st) {
+  FastGeom g;
+  g.N = n; g.Hs = h; g.Ws = w; g.C = cout; g.lds = dy_pp ? cout : ldy;
+  g.KW = 3; g.Hd = h; g.Wd = w; g.dsd = 1; g.ldd = dx_pp ? cin : ldx; g.K = cin;
+  g.ldw = 9 * cout; g.ldr = ldr; g.slope = slope; g.accumulate = 0;
+  g.flags = (residual ? SRHIP_EPI_RESIDUAL : 0) | (actmask ? SRHIP_EPI_ACTMASK : 0) | SRHIP_EPI_GRADDATA;
+  g.ss = 1; g.dhs = -1; g.dws = -1; g.khs = 1; g.kws = 1;
+  g.dst_identity = 1;
+  // stride 1, pad 1, 3 x 3: ONE phase (fast_conv2d_dgrad's general code with stride = 1, pad = 1): tap th reads dy row hh + 1 - th
+  g.ph = 0; g.pw = 0; g.OH = h; g.OW = w; g.kh0 = 0; g.kw0 = 0;
+  g.TH = 3; g.TW = 3;
+  g.dh0 = 1; g.dw0 = 1;
+  const long M = (long)n * h * w;
+  SRHIP_REQUIRE(M < (1L << 31), "conv2d_dgrad_pp: pixel count overflows int32");
+  g.M = (int)M;
+  const long ppx = pp_plane_pixels(n, h, w);
+  g.src_pp = dy_pp; g.dst_pp = dx_pp;
+  g.src_guard = g.dst_guard = pp_guard(w);
+  if (dy_pp) {
+    SRHIP_REQUIRE(ppx * cout * 4L < (1L << 31), "conv2d_dgrad_pp: dy planes >= 2 GiB");
+    g.src_plane_bytes = (unsigned)(ppx * cout * 2L);
+    g.src_bytes = 2u * g.src_plane_bytes;
+  } else {
+    SRHIP_REQUIRE(bytes_ok(M, ldy, cout, &g.src_bytes), "conv2d_dgrad_pp: dy tensor >= 2 GiB");
+  }
+  if (dx_pp) {
+    SRHIP_REQUIRE(ppx * cin * 4L < (1L << 31), "conv2d_dgrad_pp: dx planes >= 2 GiB");
+    g.dst_plane_bytes = (unsigned)(ppx * cin * 2L);
+  }
+  g.w_bytes = (unsigned)((long)cin * g.ldw * 4);
+  return run_fast(static_cast<const float*>(dy), packed, nullptr, residual, nullptr, nullptr, static_cast<const float*>(actmask),
+                  static_cast<float*>(dx), g, st);
 }
 
 int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,

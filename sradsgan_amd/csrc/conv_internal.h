@@ -67,6 +67,10 @@ int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, cons
 int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const float* residual, const float* actmask,
                       float slope, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldy,
                       int ldx, int ldr, int accumulate, hipStream_t st);
+int fast_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const float* bias, void* y, int y_pp, int n, int h, int w, int cin,
+                       int cout, int ldx, int ldy, float slope, int flags, hipStream_t st);
+int fast_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,
+                         float slope, int n, int h, int w, int cin, int cout, int ldy, int ldx, int ldr, hipStream_t st);
 size_t fast_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad);
 int fast_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, const float* xrow, const float* xchan,
                       int accumulate, void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int ldx, int ldy,

@@ -40,12 +40,19 @@ extern int g_fast_ablate;
 // maximum, first arg-max pixel -- and writes one partial per (image, tile, wave row): the CLAM pooling partials of the RAB tail
 // (clam_pool_partial_kernel's job: a 24 MB read and a launch per RAB) as three more counted stores of the producing conv.
 // pool_out: [3 sections: sum | max | arg][image][2 * tiles per image][64], section stride pool_sec bytes.
-template <int BN, int EPI, int PROD = 0, int ABL = 0, int POOL = 0>
+// SRCPP / DSTPP (round 5): the source / the destination are padded split-bf16 planes (conv_wgrad_flat.hip).  A pp source arrives as
+// the very LDS image the in-place split would have left (a lane's 16-byte quad = 8 hi or 8 lo halves of one pixel), so the split and
+// its LDS round trip are skipped; a pp destination takes the epilogue's fp32 rows as 8-channel hi | lo stores (the same bytes as the
+// fp32 row), and its activation mask (the dgrad of a conv whose producer's LeakyReLU output is kept as planes) is read from the
+// mask tensor's hi plane at the same offsets.
+template <int BN, int EPI, int PROD = 0, int ABL = 0, int POOL = 0, int SRCPP = 0, int DSTPP = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_pers_kernel(
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
     PatchGeom pg, int nblk_m, int nblk_n, unsigned dst_bytes, int ndst16, float* __restrict__ pool_out, unsigned pool_sec) {
   static_assert(POOL == 0 || (BN == 64 && PROD == 0 && ABL == 0), "pooling epilogue: 64-wide tile, split-bf16");
+  static_assert((SRCPP == 0 && DSTPP == 0) || (PROD == 0 && ABL == 0), "padded planes: split-bf16 only");
+  static_assert(DSTPP == 0 || POOL == 0, "a pp destination has no pooling epilogue");
   constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int XB = (ABL & 128) ? 2 : 1, XA = (ABL & 256) ? 2 : 1;   // ablations 128 / 256: every B / A DMA issued twice (marginal cost of the streams)
   constexpr bool DIRECT = (ABL & 64) != 0;          // ablation 64: epilogue straight from the accumulators with the MFMA operand roles swapped (see the header)
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int pr_, pc_;
     patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
     pix_tab[tid] = (pr_ << 16) | pc_;
-    rel_tab[tid] = pr_ < pg.PH ? (unsigned)((pr_ * g.Wd + pc_) * g.ldd) * 4u : F_OOB;
+    rel_tab[tid] = pr_ < pg.PH ? (DSTPP ? (unsigned)((pr_ * (g.Wd + 1) + pc_) * g.K) * 2u : (unsigned)((pr_ * g.Wd + pc_) * g.ldd) * 4u) : F_OOB;
   }
   if ((EPI >= 0 ? EPI : g.flags) & SRHIP_EPI_BIAS)
     for (int i = tid; i < g.K; i += 256) bias_s[i] = bias[i];
@@ -135,6 +142,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     for (int k = 0; k < MAXP; ++k) {
       const int pi = pij[k] >> 16, pj = pij[k] & 0xffff;
       const int sh = t.oh0 + pg.lo_h + pi, sw = t.ow0 + pg.lo_w + pj;
+      if (SRCPP) {       // the zero pad row / column / guard ARE the halo: only positions beyond them are out of range
+        const bool ok = t.n0 >= 0 && pij[k] >= 0 && sh >= -1 && sh <= g.Hs && sw >= -1 && sw <= g.Ws;
+        aoffb[k] = ok ? (unsigned)(aq & 1) * g.src_plane_bytes +
+                            (unsigned)((g.src_guard + (t.img * (g.Hs + 1) + sh) * (g.Ws + 1) + sw) * g.C + (aq >> 1) * 8) * 2u
+                      : F_OOB;
+        continue;
+      }
       const bool ok = t.n0 >= 0 && pij[k] >= 0 && sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws;
       aoffb[k] = ok ? (unsigned)(((t.img * g.Hs + sh) * g.Ws + sw) * g.lds + aq * 4) * 4u : F_OOB;
     }
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
   };
   auto issue_a = [&](int buf, int k, unsigned coff) {   // one 1 KiB piece of a patch; coff = byte offset of the chunk's channels
-    lds_dma16_buf(aoffb[k] + coff, rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));
+    lds_dma16_buf(aoffb[k] + (SRCPP ? coff >> 1 : coff), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));   // (a chunk = 16 channels: 64 bytes of fp32, 32 of a plane)
   };
   auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
     const unsigned wk = TILED ? (unsigned)(wtap[tap] + cc * wchunk) : (unsigned)((wtap[tap] + cc * BK) * 4);
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       for (int j = 0; j < BPW; ++j) lds_dma16_buf(F_OOB, rs_b, b_dst + ((TAP + 2) % 3) * BSTAGE_B + j * 1024);
     } else if (TAP + 2 < 9) issue_b((TAP + 2) % 3, TAP + 2, cc);
     else issue_b((TAP + 2) % 3, TAP + 2 - 9, b_ncc);
-    if (!(ABL & 2) && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);
+    if (!SRCPP && !(ABL & 2) && TAP >= 2 && TAP - 2 < MAXP) convert_piece(pbuf ^ 1, TAP - 2);
     const char* pb = lds + pbuf * PATCH_B;
     const char* sb = lds + (TAP % 3) * BSTAGE_B;
     bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
@@ -522,6 +536,101 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     zero_acc();
   };
 
+  // ---- epilogue onto padded planes: the same four 16-row passes, a lane serves 8 channels (two float4 of the staged row) of
+  // 64 / OPR rows per pass and stores them as 8 hi + 8 lo halves: NS stores per tile like the fp32 form
+  auto epilogue_pp = [&](const TileAt& t) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int OPR = WTN / 8;                        // 8-channel groups per staged row
+    constexpr int NRP = 16 * OPR / 64;                  // rows per lane per pass
+    static_assert(2 * NRP == NRD, "hi + lo stores = the fp32 form's store count");
+    float* wl = reinterpret_cast<float*>(wave < 3 ? lds + PATCH_B + wave * STG_B : lds + RING0 + 2 * BSTAGE_B);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int l31e = ln & 31, khe = ln >> 5;
+    const int oq = ln & (OPR - 1), rsub = ln / OPR;
+    const int n = t.n0 + wn * WTN + oq * 8;
+    const bool nok = n < g.K;
+    const int ns = nok ? n : 0;
+    const unsigned tile_base = (unsigned)((g.dst_guard + (t.img * (g.Hd + 1) + t.oh0) * (g.Wd + 1) + t.ow0) * g.K + n) * 2u;
+    const bool interior = t.oh0 + pg.PH <= g.OH && t.ow0 + pg.PW <= g.OW;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (flags & SRHIP_EPI_BIAS) {
+      b0 = *reinterpret_cast<const float4*>(bias_s + ns);
+      b1 = *reinterpret_cast<const float4*>(bias_s + ns + 4);
+    }
+    auto pass_offsets = [&](int p, unsigned (&doff)[NRP], bool (&okv)[NRP]) {
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) {
+        const int rr = wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + i * (64 / OPR) + rsub;
+        const unsigned rel = rel_tab[rr];
+        bool ok = nok && rel < F_OOB;
+        if (!interior) {
+          const int pt = pix_tab[rr];
+          ok = ok && t.oh0 + (pt >> 16) < g.OH && t.ow0 + (pt & 0xffff) < g.OW;
+        }
+        okv[i] = ok;
+        doff[i] = ok ? tile_base + rel : 0u;
+      }
+    };
+    u32x4 am[2][NRP];                                   // mask = the hi halves of the producer's activation output (same geometry)
+    unsigned doffs[2][NRP];
+    bool oks[2][NRP];
+    pass_offsets(0, doffs[0], oks[0]);
+    if (flags & SRHIP_EPI_ACTMASK) {
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) am[0][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + doffs[0][i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int tt = p >> 1, rb = (p & 1) * 8, cur = p & 1, nx = cur ^ 1;
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
+      if (p < 3) {
+        pass_offsets(p + 1, doffs[nx], oks[nx]);
+        if (flags & SRHIP_EPI_ACTMASK) {
+#pragma unroll
+          for (int i = 0; i < NRP; ++i) am[nx][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + doffs[nx][i]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) {
+        const int row = i * (64 / OPR) + rsub;
+        const float4 v0 = *reinterpret_cast<const float4*>(wl + row * WTN + oq * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(wl + row * WTN + oq * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (flags & SRHIP_EPI_BIAS) {
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (flags & SRHIP_EPI_LRELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.slope;
+        }
+        if (flags & SRHIP_EPI_ACTMASK) {
+          const unsigned mv[4] = {am[cur][i].x, am[cur][i].y, am[cur][i].z, am[cur][i].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a = __uint_as_float((j & 1) ? (mv[j >> 1] & 0xffff0000u) : (mv[j >> 1] << 16));
+            v[j] = a > 0.f ? v[j] : v[j] * g.slope;
+          }
+        }
+        bf16x8_t hi, lo;
+        split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+        const unsigned doff = doffs[cur][i];
+        const bool ok = oks[cur][i];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_d, ok ? doff : F_OOB + 32u * (unsigned)(p * NRP + i), 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_d, ok ? doff + g.dst_plane_bytes : F_OOB + 32u * (unsigned)(p * NRP + i) + 16u, 0, 2);
+      }
+      if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    zero_acc();
+  };
+
   // ---- the tile walk ----
   TileAt cur = decode(blockIdx.x), nxt = cur;
   set_a(cur);
@@ -538,8 +647,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     __builtin_amdgcn_raw_buffer_store_b128(z, rs_d, F_OOB + 16u * i, 0, 0);   // distinct offsets: identical stores would be merged
   }
   wait_vmcnt<XB * BPW + NS>();
+  if (!SRCPP) {
 #pragma unroll
-  for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+    for (int k = 0; k < MAXP; ++k) convert_piece(0, k);
+  }
   for (int vt = blockIdx.x; vt < ntiles; vt += (int)gridDim.x) {
     do_chunk(IC<1>(), IC<0>(), 0, (unsigned)(BK * 4), 1, false, cur);
     for (int cc = 1; cc + 2 < CC; cc += 2) {        // CC is even: odd chunks live in patch buffer 1, even ones in 0
@@ -551,7 +662,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     else nxt.n0 = -1;
     set_a(nxt);                                     // this tile's patches are all fetched: taps 0..2 fetch the next tile's first
     do_chunk(IC<0>(), IC<1>(), CC - 1, 0u, 0, true, nxt);
-    if (DIRECT) epilogue_direct(cur);
+    if (DSTPP) epilogue_pp(cur);
+    else if (DIRECT) epilogue_direct(cur);
     else epilogue(cur);
     cur = nxt;
   }
@@ -593,6 +705,49 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
   const long ntiles = (long)nbm * nbn;
   int slots = 3 * num_cu();
   slots -= slots % 8;                               // keeps a block's XCD (blockIdx % 8) fixed over its tiles
+  if (g.src_pp || g.dst_pp) {
+    // padded-plane operands (round 5): always this kernel -- min(tiles, slots) blocks --, split-bf16 only.  Instantiated: what the RAB
+    // uses (conv1 fprop: fp32 -> planes with bias + LeakyReLU; conv2 dgrad: fp32 -> planes with the activation mask; conv2 fprop:
+    // planes -> fp32, plain / bias, with or without the pooling partials; conv1 dgrad: planes -> fp32 + residual) and run-time-flag forms.
+    if (prod != 0) return -1;
+    const long pdb = g.dst_pp ? 2L * g.dst_plane_bytes : dbytes;
+    if (pdb >= (1L << 31)) return -1;
+    const unsigned pdbu = (unsigned)pdb;
+    const int pgrid = g_pers_grid > 0 ? (int)(g_pers_grid < ntiles ? g_pers_grid : ntiles) : (int)(ntiles < slots ? ntiles : slots);
+#define SRHIP_PPX(BN_, EPI_, POOL_, SRC_, DST_, PO_, PS_)                                                                        \
+  do {                                                                                                                           \
+    hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, 0, 0, POOL_, SRC_, DST_>), dim3(pgrid), dim3(256), 0, st, src, wsplit, bias, \
+                       residual, actmask, dst, g, pg, nbm, nbn, pdbu, ndst16, PO_, PS_);                                         \
+    return check_launch("conv_patch_pers_pp");                                                                                   \
+  } while (0)
+    if (g.src_pp && !g.dst_pp && !wide) {
+      if (g_pool_req.out != nullptr && nbn == 1 && g.K == 64 && (eflags == 0 || eflags == SRHIP_EPI_BIAS) &&
+          2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW && ntiles <= 2 * (slots / 3)) {
+        const int nseg = 2 * pg.tiles_h * pg.tiles_w;
+        if ((size_t)g.N * nseg * 64 * 4 <= (size_t)g_pool_req.sec_bytes) {
+          float* po = g_pool_req.out;
+          const unsigned ps = g_pool_req.sec_bytes;
+          g_pool_req.served_nseg = nseg;
+          if (eflags == 0) SRHIP_PPX(64, 0, 1, 1, 0, po, ps);
+          SRHIP_PPX(64, 1, 1, 1, 0, po, ps);
+        }
+      }
+      if (eflags == 0) SRHIP_PPX(64, 0, 0, 1, 0, nullptr, 0u);
+      if (eflags == SRHIP_EPI_BIAS) SRHIP_PPX(64, 1, 0, 1, 0, nullptr, 0u);
+      if (eflags == SRHIP_EPI_RESIDUAL) SRHIP_PPX(64, 4, 0, 1, 0, nullptr, 0u);
+      SRHIP_PPX(64, -1, 0, 1, 0, nullptr, 0u);
+    }
+    if (g.src_pp && !g.dst_pp) SRHIP_PPX(128, -1, 0, 1, 0, nullptr, 0u);
+    if (!g.src_pp && wide) {
+      if (eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_PPX(128, 3, 0, 0, 1, nullptr, 0u);
+      if (eflags == SRHIP_EPI_ACTMASK) SRHIP_PPX(128, 32, 0, 0, 1, nullptr, 0u);
+      SRHIP_PPX(128, -1, 0, 0, 1, nullptr, 0u);
+    }
+    if (!g.src_pp) SRHIP_PPX(64, -1, 0, 0, 1, nullptr, 0u);
+    if (wide) SRHIP_PPX(128, -1, 0, 1, 1, nullptr, 0u);
+    SRHIP_PPX(64, -1, 0, 1, 1, nullptr, 0u);
+#undef SRHIP_PPX
+  }
   if (g_pers_grid < 0) return -1;
   // Fewer tiles than block slots (round 4, srhip_debug_set(11, 0) = the one-tile kernels of rounds 1-3 instead): this kernel still
   // wins -- bias in LDS, staged non-temporal epilogue, counted waits -- with ONE tile per block for the 64-wide tile (768 tiles at

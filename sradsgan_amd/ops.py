@@ -533,6 +533,59 @@ def pp_to_f32(pp):
     return out
 
 
+def conv2d_pp_ok(n, cin, h, w, cout):
+    """The persistent patch kernel takes this 3x3 stride-1 pad-1 conv with padded-plane operands (split-bf16 mode)."""
+    return bool(_hip.lib().srhip_conv2d_pp_ok(n, h, w, cin, cout))
+
+
+def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
+    """3x3 stride-1 pad-1 forward with padded-plane operands: x a PP or fp32 NHWC; out_pp = PP buffer to fill (then the result is that
+    PP) or None (fp32 result).  pool=True (fp32 result of 64 channels): also the CLAM pooling partials, as conv2d_fwd_pool_raw."""
+    cout, cin = w.shape[0], w.shape[1]
+    n, _, h, wd = x.shape
+    xpp = isinstance(x, PP)
+    if not xpp:
+        _require_gpu(x, 'conv2d_fwd_pp')
+        x = nhwc(x)
+    dev = x.buf.device if xpp else x.device
+    y = out_pp if out_pp is not None else torch.empty(n, cout, h, wd, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    flags = 0
+    b = None
+    if bias is not None:
+        flags |= EPI_BIAS
+        b = bias.detach().contiguous()
+    if slope is not None:
+        flags |= EPI_LRELU
+    lib = _hip.lib()
+    pl, sec, nseg = None, 0, ctypes.c_int(0)
+    if pool:
+        sec = n * lib.srhip_clam_pool_max_segments() * 64 * 4
+        pl = torch.empty(3 * sec // 4, device=dev, dtype=torch.float32)
+    _hip.check(lib.srhip_conv2d_fwd_pp(ctypes.c_void_p(x.data_ptr()), int(xpp), _p(packed_weight(w, 0)), _p(b), ctypes.c_void_p(y.data_ptr()),
+                                      int(out_pp is not None), _p(pl), sec, ctypes.byref(nseg), n, h, wd, cin, cout, float(slope or 0.0), flags,
+                                      _stream()), 'conv2d_fwd_pp')
+    return (y, (pl, sec, nseg.value)) if pool else y
+
+
+def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=None):
+    """3x3 stride-1 pad-1 data gradient with padded-plane operands: dy a PP or fp32 NHWC; out_pp = PP buffer to fill, with
+    actmask = the PP of the LeakyReLU output that fed the forward conv; or fp32 result (+ residual)."""
+    cout, cin = w.shape[0], w.shape[1]
+    n, _, h, wd = dy.shape
+    ypp = isinstance(dy, PP)
+    if not ypp:
+        _require_gpu(dy, 'conv2d_dgrad_pp')
+        dy = nhwc(dy)
+    dev = dy.buf.device if ypp else dy.device
+    dx = out_pp if out_pp is not None else torch.empty(n, cin, h, wd, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    if residual is not None:
+        residual = nhwc(residual)
+    _hip.check(_hip.lib().srhip_conv2d_dgrad_pp(ctypes.c_void_p(dy.data_ptr()), int(ypp), _p(packed_weight(w, 1)), ctypes.c_void_p(dx.data_ptr()),
+                                                int(out_pp is not None), _p(residual), ctypes.c_void_p(actmask.data_ptr()) if actmask is not None else None,
+                                                float(slope), n, h, wd, cin, cout, _stream()), 'conv2d_dgrad_pp')
+    return dx
+
+
 def conv2d_wgrad_pp_raw(items, accumulate=True, on_stream=None):
     """items: [(x, dy, dw_buf, db_buf or None)] -- 1..4 weight gradients of ONE 3x3 stride-1 pad-1 shape by one launch of the flat
     kernels (srhip_conv2d_wgrad_pp): x and / or dy are PP objects (padded planes), an operand that is not is fp32 NHWC."""

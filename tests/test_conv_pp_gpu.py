@@ -1,0 +1,99 @@
+"""The persistent patch kernel with padded split-bf16 plane operands (csrc/conv_patch_pers.hip SRCPP / DSTPP, ABI 9) against the same
+kernel family on fp32 tensors: a pp source carries exactly the hi | lo split the kernel forms itself, so forward / data-gradient
+results are BIT-IDENTICAL to the fp32-operand calls; a pp destination holds the split of the fp32 result (hi bit-exact, hi + lo
+within 2^-16).  Shapes: the RAB's four launches (conv1 fprop 64 -> 256 bias + LeakyReLU -> planes; conv2 fprop planes -> 64
+(+ pooling partials); conv2 dgrad 64 -> 256 with the activation mask -> planes; conv1 dgrad planes -> 64 + residual) on ragged
+images, several tiles per block, partial edge tiles.  Replaces sradsgan.py:222-223, 250-252 like srhip_conv2d_fwd / _dgrad."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+CASES = [(2, 23, 37), (1, 54, 54), (3, 9, 20), (2, 17, 16), (5, 27, 27), (2, 24, 24), (16, 54, 54)]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_rab_convs_on_padded_planes_match_the_fp32_operand_kernels(case):
+    from sradsgan_amd import ops, _hip
+    n, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = _cl(torch.randn(n, 64, h, w, generator=g))
+    w1 = torch.nn.Parameter((torch.randn(256, 64, 3, 3, generator=g) * 0.05).to(DEV))
+    b1 = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    w2 = torch.nn.Parameter((torch.randn(64, 256, 3, 3, generator=g) * 0.05).to(DEV))
+    b2 = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    du = _cl(torch.randn(n, 64, h, w, generator=g))
+    gres = _cl(torch.randn(n, 64, h, w, generator=g))
+    lib = _hip.lib()
+    with ops.conv_math('bf16x3'):
+        assert ops.conv2d_pp_ok(n, 64, h, w, 256) and ops.conv2d_pp_ok(n, 256, h, w, 64)
+        for grid in (0, 5):                                  # 5: several tiles per block on small images (srhip_debug_set(5, n))
+            lib.srhip_debug_set(5, grid)
+            lib.srhip_debug_set(0, -2)                       # the fp32-tensor reference through the patch kernels at any size (small
+            try:                                             # problems otherwise take the exact-fp32 register-staged kernel)
+                # reference: the fp32-tensor path
+                t = ops.conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
+                u = ops.conv2d_fwd_raw(t, w2, b2, 1, 1)
+                dt = ops.conv2d_dgrad_raw(du, w2, tuple(t.shape), 1, 1, None, t, 0.2)
+                dx = ops.conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, gres)
+                # planes
+                t_pp = ops.conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV))
+                t_ref = ops.pp_from_f32(t)
+                assert torch.equal(t_pp.buf, t_ref.buf)                        # the split of the fp32 result, pads untouched (zero)
+                u_pp = ops.conv2d_fwd_pp_raw(t_pp, w2, b2)
+                assert torch.equal(u_pp, u)
+                u_pool, (pool, sec, nseg) = ops.conv2d_fwd_pp_raw(t_pp, w2, b2, pool=True)
+                assert torch.equal(u_pool, u) and nseg > 0
+                if ops.pool_epilogue_ok(t, w2):
+                    u2, (pool2, sec2, nseg2) = ops.conv2d_fwd_pool_raw(t, w2, b2)
+                    assert nseg2 == nseg and sec2 == sec
+                    for k in range(3):
+                        a = pool[k * sec // 4:k * sec // 4 + n * nseg * 64]
+                        b = pool2[k * sec // 4:k * sec // 4 + n * nseg * 64]
+                        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+                dt_pp = ops.conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV))
+                assert torch.equal(dt_pp.buf, ops.pp_from_f32(dt).buf)
+                dx_pp = ops.conv2d_dgrad_pp_raw(dt_pp, w1, residual=gres)
+                assert torch.equal(dx_pp, dx)
+            finally:
+                lib.srhip_debug_set(5, 0)
+                lib.srhip_debug_set(0, 0)
+        # a reused buffer keeps its zero padding: write other data into the same planes, pads still zero
+        ops.conv2d_fwd_pp_raw(-x, w1, b1, 0.2, out_pp=t_pp)
+        guard = lib.srhip_pp_guard(w)
+        grid_ = t_pp.buf[0][guard:guard + n * (h + 1) * (w + 1)].view(n, h + 1, w + 1, 256).float()
+        assert float(grid_[:, h].abs().max()) == 0.0 and float(grid_[:, :, w].abs().max()) == 0.0
+        assert float(t_pp.buf[:, :guard].float().abs().max()) == 0.0
+
+
+def test_tiny_image_on_padded_planes_against_fp64():
+    """3 x 5 pixels: the fp32-tensor path has no patch kernel at this size (exact-fp32 register-staged kernel), the padded-plane path
+    takes the patch kernel with a 12 %-filled tile: compared with fp64 instead of bit for bit."""
+    from sradsgan_amd import ops
+    n, h, w = 1, 3, 5
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 64, h, w, generator=g)
+    w1 = (torch.randn(256, 64, 3, 3, generator=g) * 0.05)
+    b1 = torch.randn(256, generator=g) * 0.1
+    w2 = (torch.randn(64, 256, 3, 3, generator=g) * 0.05)
+    du = torch.randn(n, 64, h, w, generator=g)
+    F = torch.nn.functional
+    t64 = F.leaky_relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1), 0.2)
+    u64 = F.conv2d(t64, w2.double(), None, padding=1)
+    dt64 = F.conv_transpose2d(du.double(), w2.double(), padding=1) * torch.where(t64 > 0, 1.0, 0.2)
+    dx64 = F.conv_transpose2d(dt64, w1.double(), padding=1)
+    rel = lambda a, b: float((a.cpu().double() - b).abs().max() / b.abs().max())
+    with ops.conv_math('bf16x3'):
+        w1p, w2p = torch.nn.Parameter(w1.to(DEV)), torch.nn.Parameter(w2.to(DEV))
+        t_pp = ops.conv2d_fwd_pp_raw(_cl(x), w1p, b1.to(DEV), 0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV))
+        assert rel(ops.pp_to_f32(t_pp), t64) < 2e-5
+        assert rel(ops.conv2d_fwd_pp_raw(t_pp, w2p, None), u64) < 2e-5
+        dt_pp = ops.conv2d_dgrad_pp_raw(_cl(du), w2p, actmask=t_pp, slope=0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV))
+        assert rel(ops.pp_to_f32(dt_pp), dt64) < 2e-5
+        assert rel(ops.conv2d_dgrad_pp_raw(dt_pp, w1p), dx64) < 3e-5
