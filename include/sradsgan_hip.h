@@ -164,9 +164,10 @@ int srhip_conv2d_wgrad_multi(int nprob, const float* const* x, const float* cons
  * Replaces nothing new in the reference: it is the autograd of the RAB convs (sradsgan.py:222-223, 250-252) like
  * srhip_conv2d_wgrad; what changes is the FORMAT the two 256-channel tensors inside a RAB (t = LeakyReLU(conv1 x) and its
  * gradient) are kept in between the block's own kernels.
- * pp of an NHWC tensor [N,H,W,C] (C % 8 == 0): 2 bf16 planes (hi = bf16(v), lo = bf16(v - hi)) of
- * srhip_pp_plane_pixels(n,h,w) pixel rows of C channels each: srhip_pp_guard(w) zero rows, then pixel (n,y,x) at row
- * (n*(H+1) + y)*(W+1) + x -- one zero pixel behind every image row, one zero row behind every image --, then a zero tail.
+ * pp of an NHWC tensor [N,H,W,C] (C % 8 == 0): srhip_pp_plane_pixels(n,h,w) pixel rows of C * 4 bytes; a row holds, for every
+ * 8 channels, the 8 hi halves (hi = bf16(v)) followed by the 8 lo halves (lo = bf16(v - hi)) -- 32 bytes, the split the bf16x3
+ * kernels form anyway.  srhip_pp_guard(w) zero rows come first, then pixel (n,y,x) at row (n*(H+1) + y)*(W+1) + x -- one zero
+ * pixel behind every image row, one zero row behind every image --, then a zero tail.
  * The PAD / GUARD / TAIL ROWS MUST BE ZERO and no entry point ever writes them: allocate the buffer zeroed once and reuse it.
  * srhip_pp_from_f32 / srhip_pp_to_f32 convert (valid pixels only; to_f32 returns hi + lo).
  * srhip_conv2d_wgrad_pp: nprob (1..4) weight gradients of ONE 3x3 stride-1 pad-1 shape in one launch, split-bf16 arithmetic.

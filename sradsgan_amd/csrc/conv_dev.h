@@ -22,7 +22,7 @@ struct FastGeom {
   int flags, accumulate, dst_identity;
   unsigned src_bytes, w_bytes;
   // padded split-bf16 planes (conv_wgrad_flat.hip) as source / destination of the persistent patch kernel (round 5): the tensor is
-  // [2 planes][guard + N (H+1) (W+1) + tail][channels] bf16; Hs / Ws (Hd / Wd) stay the LOGICAL image size
+  // [guard + N (H+1) (W+1) + tail] pixel rows of channels * 4 bytes (per 8 channels: 8 hi | 8 lo halves); Hs / Ws (Hd / Wd) stay the LOGICAL image size
   int src_pp = 0, dst_pp = 0, src_guard = 0, dst_guard = 0;
   unsigned src_plane_bytes = 0, dst_plane_bytes = 0;
 };

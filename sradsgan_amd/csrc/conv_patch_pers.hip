@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     int pr_, pc_;
     patch_pixel(tid, pg.PH, pg.PW, pg.gmap, pr_, pc_);
     pix_tab[tid] = (pr_ << 16) | pc_;
-    rel_tab[tid] = pr_ < pg.PH ? (DSTPP ? (unsigned)((pr_ * (g.Wd + 1) + pc_) * g.K) * 2u : (unsigned)((pr_ * g.Wd + pc_) * g.ldd) * 4u) : F_OOB;
+    rel_tab[tid] = pr_ < pg.PH ? (DSTPP ? (unsigned)((pr_ * (g.Wd + 1) + pc_) * g.K) * 4u : (unsigned)((pr_ * g.Wd + pc_) * g.ldd) * 4u) : F_OOB;
   }
   if ((EPI >= 0 ? EPI : g.flags) & SRHIP_EPI_BIAS)
     for (int i = tid; i < g.K; i += 256) bias_s[i] = bias[i];
@@ -144,9 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       const int sh = t.oh0 + pg.lo_h + pi, sw = t.ow0 + pg.lo_w + pj;
       if (SRCPP) {       // the zero pad row / column / guard ARE the halo: only positions beyond them are out of range
         const bool ok = t.n0 >= 0 && pij[k] >= 0 && sh >= -1 && sh <= g.Hs && sw >= -1 && sw <= g.Ws;
-        aoffb[k] = ok ? (unsigned)(aq & 1) * g.src_plane_bytes +
-                            (unsigned)((g.src_guard + (t.img * (g.Hs + 1) + sh) * (g.Ws + 1) + sw) * g.C + (aq >> 1) * 8) * 2u
-                      : F_OOB;
+        aoffb[k] = ok ? (unsigned)((g.src_guard + (t.img * (g.Hs + 1) + sh) * (g.Ws + 1) + sw) * g.C + aq * 4) * 4u : F_OOB;   // quad aq = 8 hi or 8 lo halves
         continue;
       }
       const bool ok = t.n0 >= 0 && pij[k] >= 0 && sh >= 0 && sh < g.Hs && sw >= 0 && sw < g.Ws;
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
   };
   auto issue_a = [&](int buf, int k, unsigned coff) {   // one 1 KiB piece of a patch; coff = byte offset of the chunk's channels
-    lds_dma16_buf(aoffb[k] + (SRCPP ? coff >> 1 : coff), rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));   // (a chunk = 16 channels: 64 bytes of fp32, 32 of a plane)
+    lds_dma16_buf(aoffb[k] + coff, rs_a, a_dst + buf * PATCH_B + k * (NW * 1024));   // (a chunk = 16 channels = 64 bytes, fp32 or padded planes)
   };
   auto issue_b = [&](int stage, int tap, int cc) {  // the B tile of (chunk cc, tap)
     const unsigned wk = TILED ? (unsigned)(wtap[tap] + cc * wchunk) : (unsigned)((wtap[tap] + cc * BK) * 4);
@@ -553,7 +551,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int n = t.n0 + wn * WTN + oq * 8;
     const bool nok = n < g.K;
     const int ns = nok ? n : 0;
-    const unsigned tile_base = (unsigned)((g.dst_guard + (t.img * (g.Hd + 1) + t.oh0) * (g.Wd + 1) + t.ow0) * g.K + n) * 2u;
+    const unsigned tile_base = (unsigned)((g.dst_guard + (t.img * (g.Hd + 1) + t.oh0) * (g.Wd + 1) + t.ow0) * g.K + n) * 4u;   // 8 channels = 32 bytes: [8 hi | 8 lo]
     const bool interior = t.oh0 + pg.PH <= g.OH && t.ow0 + pg.PW <= g.OW;
     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
     if (flags & SRHIP_EPI_BIAS) {
@@ -624,7 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         const unsigned doff = doffs[cur][i];
         const bool ok = oks[cur][i];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_d, ok ? doff : F_OOB + 32u * (unsigned)(p * NRP + i), 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_d, ok ? doff + g.dst_plane_bytes : F_OOB + 32u * (unsigned)(p * NRP + i) + 16u, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_d, ok ? doff + 16u : F_OOB + 32u * (unsigned)(p * NRP + i) + 16u, 0, 2);
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

@@ -1,9 +1,11 @@
 // Weight gradient of stride-1 pad-1 3x3 convolutions in split-bf16 as ONE FLAT GEMM over padded pixels (round 5), and the
 // "padded planes" activation format it is built on.
 //
-// Padded planes (pp) of an NHWC tensor [N,H,W,C]: two bf16 planes -- hi = bf16(v), lo = bf16(v - hi), the split the
-// bf16x3 kernels form anyway -- each [guard + N*(H+1)*(W+1) + tail][C]: every image row carries ONE zero pixel behind it, every
-// image ONE zero row, `guard` zero pixels lie in front of pixel (0,0,0) and a zero tail behind the last.  With that padding the
+// Padded planes (pp) of an NHWC tensor [N,H,W,C]: the split-bf16 form of every value -- hi = bf16(v), lo = bf16(v - hi), the split
+// the bf16x3 kernels form anyway -- as [guard + N*(H+1)*(W+1) + tail] pixel rows of C * 4 bytes, a row = for every 8 channels the 8 hi
+// halves followed by the 8 lo halves (32 bytes: exactly the LDS row image the patch kernels' in-place split leaves, so a 16-channel
+// chunk of a pixel is one 64-byte run like in the fp32 tensor).  Every image row carries ONE zero pixel behind it, every image ONE
+// zero row, `guard` zero pixels lie in front of pixel (0,0,0) and a zero tail behind the last.  With that padding the
 // nine taps of a 3x3 window are FLAT shifts of the pixel index:
 //     dW[co][ci][kh][kw] = sum over flat p of dy[p][co] * x[p + (kh-1)*(W+1) + (kw-1)][ci]
 // (a shift that leaves the image lands on a zero pixel), so the K loop of the weight gradient needs no row / column / image
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
     const int lg = (((pg >> 2) ^ (r & 3)) << 2) | (pg & 3);  // logical 8-channel granule this lane's slot holds
     const int ch = (APL ? m0 : ci_base) + lg * 8;
     const bool live = ch < plC && (k < 2 || wave == 0);
-    pl_voff[k] = live ? (unsigned)plane * g.plane_bytes + (unsigned)(r * plC + ch) * 2u : F_OOB;
+    pl_voff[k] = live ? (unsigned)(r * plC + ch) * 4u + (unsigned)plane * 16u : F_OOB;      // pixel row = plC * 4 bytes: per 8 channels [8 hi | 8 lo]
     pl_dst[k] = __builtin_amdgcn_readfirstlane(lds_base + piece * 1024);
   }
   // fp32 slots: per-lane walk of the padded grid (n, h, w) -> pixel of the UNPADDED tensor; a pad position is an out-of-range lane
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
   int c_issue = c_begin;
   auto issue = [&](int stage) {                              // the DMAs of chunk c_issue into `stage`
     const unsigned so = stage * STAGE_B;
-    const unsigned soff = (unsigned)(g.guard + c_issue * 16 + (APL ? 0 : shiftB)) * (unsigned)plC * 2u;
+    const unsigned soff = (unsigned)(g.guard + c_issue * 16 + (APL ? 0 : shiftB)) * (unsigned)plC * 4u;
 #pragma unroll
     for (int k = 0; k < NPL; ++k)
       if (k < 2 || wave == 0) dma_s(pl_voff[k], soff, rs_pl, pl_dst[k] + so);
@@ -485,21 +487,21 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
   bool d_isx[3];
   {
     // wide image (256-byte rows, 128 channels): piece = 4 rows x 16 granules; narrow (128-byte rows, 64 channels): 8 rows x 8 granules
-    auto wide = [&](int piece_in_plane_pair, int nrows, int chan0, int chanC, unsigned plane_b, unsigned& voff) {
+    auto wide = [&](int piece_in_plane_pair, int nrows, int chan0, int chanC, unsigned, unsigned& voff) {
       const int rr = 4 * piece_in_plane_pair + (lane >> 4);                    // row of the [hi rows | lo rows] image
       const int plane = rr >= nrows ? 1 : 0, r = rr - nrows * plane;
       const int pgl = lane & 15;
       const int lg = (((pgl >> 2) ^ (r & 3)) << 2) | (pgl & 3);
       const int ch = chan0 + lg * 8;
-      voff = (rr < 2 * nrows && ch < chanC) ? (unsigned)plane * plane_b + (unsigned)(r * chanC + ch) * 2u : F_OOB;
+      voff = (rr < 2 * nrows && ch < chanC) ? (unsigned)(r * chanC + ch) * 4u + (unsigned)plane * 16u : F_OOB;
     };
-    auto narrow = [&](int piece_in_plane_pair, int nrows, int chan0, int chanC, unsigned plane_b, unsigned& voff) {
+    auto narrow = [&](int piece_in_plane_pair, int nrows, int chan0, int chanC, unsigned, unsigned& voff) {
       const int rr = 8 * piece_in_plane_pair + (lane >> 3);
       const int plane = rr >= nrows ? 1 : 0, r = rr - nrows * plane;
       const int pgl = lane & 7;
       const int lg = (((pgl >> 2) ^ ((r >> 1) & 1)) << 2) | (pgl & 3);
       const int ch = chan0 + lg * 8;
-      voff = (rr < 2 * nrows && ch < chanC) ? (unsigned)plane * plane_b + (unsigned)(r * chanC + ch) * 2u : F_OOB;
+      voff = (rr < 2 * nrows && ch < chanC) ? (unsigned)(r * chanC + ch) * 4u + (unsigned)plane * 16u : F_OOB;
     };
     if (CFG == 1) {
       // slots 0, 1: this group's dy image (8 pieces: hi 0-3, lo 4-7): pieces w4 and 4 + w4;  slot 2: x image piece `wave` (5 pieces), else scratch
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
     if (ABL & 2) voff = F_OOB;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(dst) : "memory");
   };
-  const unsigned yC2 = (unsigned)g.K * 2u, xC2 = (unsigned)g.C * 2u;
+  const unsigned yC2 = (unsigned)g.K * 4u, xC2 = (unsigned)g.C * 4u;     // bytes per pixel row of the padded tensors
   auto issue = [&](int c, int stage) {                       // chunk c (relative to c_begin; >= nk: nothing is fetched, the count stays)
     const bool live = c < nk;
     const unsigned so_y = (unsigned)(g.guard + (c_begin + c) * 16) * yC2;
@@ -743,8 +745,8 @@ __global__ __launch_bounds__(256) void pp_from_f32_kernel(const float* __restric
   bf16x8_t hi, lo;
   split_bf16x8(v0, v1, hi, lo);
   const long row = guard + ((long)nn * (h + 1) + hh) * (w + 1) + ww;
-  *reinterpret_cast<bf16x8_t*>(pp + row * c + g8 * 8) = hi;
-  *reinterpret_cast<bf16x8_t*>(pp + plane_elems + row * c + g8 * 8) = lo;
+  *reinterpret_cast<bf16x8_t*>(pp + row * 2 * c + g8 * 16) = hi;
+  *reinterpret_cast<bf16x8_t*>(pp + row * 2 * c + g8 * 16 + 8) = lo;
 }
 __global__ __launch_bounds__(256) void pp_to_f32_kernel(const __bf16* __restrict__ pp, float* __restrict__ x, int n, int h, int w, int c, int ldx,
                                                         int guard, long plane_elems) {
@@ -758,8 +760,8 @@ __global__ __launch_bounds__(256) void pp_to_f32_kernel(const __bf16* __restrict
   const long t = pix / w;
   const int hh = (int)(t % h), nn = (int)(t / h);
   const long row = guard + ((long)nn * (h + 1) + hh) * (w + 1) + ww;
-  const bf16x8_t hi = *reinterpret_cast<const bf16x8_t*>(pp + row * c + g8 * 8);
-  const bf16x8_t lo = *reinterpret_cast<const bf16x8_t*>(pp + plane_elems + row * c + g8 * 8);
+  const bf16x8_t hi = *reinterpret_cast<const bf16x8_t*>(pp + row * 2 * c + g8 * 16);
+  const bf16x8_t lo = *reinterpret_cast<const bf16x8_t*>(pp + row * 2 * c + g8 * 16 + 8);
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (float)hi[j] + (float)lo[j];
@@ -867,7 +869,7 @@ int flat_wgrad(int nprob, const void* const* x, const void* const* dy, int x_pp,
   const long ppx = pp_plane_pixels(n, h, w);
   g.nchunks = cdiv((long)n * g.Hp * g.Wp, 16);
   const FlatPlan p = flat_plan(x_pp, dy_pp, cin, cout, g.nchunks, nprob);
-  g.x_plane_bytes = (unsigned)(ppx * cin * 2L);
+  g.x_plane_bytes = (unsigned)(ppx * cin * 2L);           // (half the tensor: [rows][per 8 channels: 8 hi | 8 lo])
   g.x_pp_bytes = 2u * g.x_plane_bytes;
   if (p.kernel == 8) {
     g.plane_bytes = (unsigned)(ppx * cout * 2L);               // dy

@@ -493,8 +493,8 @@ def conv2d_wgrad_multi_raw(items, on_stream=None):
 
 # ---- padded split-bf16 planes (include/sradsgan_hip.h, ABI 9) ---------------------------------------------------------- #
 class PP:
-    """Padded planes of an NHWC tensor [n, c, h, w]: `buf` = bf16 [2, srhip_pp_plane_pixels(n, h, w), c] (hi | lo), pad / guard /
-    tail rows zero.  The kernels never write those rows, so a buffer is zeroed ONCE (pp_empty) and can then be reused for any
+    """Padded planes of an NHWC tensor [n, c, h, w]: `buf` = bf16 [srhip_pp_plane_pixels(n, h, w), 2 c] (per 8 channels: 8 hi | 8 lo
+    halves), pad / guard / tail rows zero.  The kernels never write those rows, so a buffer is zeroed ONCE (pp_empty) and can then be reused for any
     tensor of the same geometry."""
     __slots__ = ('buf', 'n', 'c', 'h', 'w')
 
@@ -514,7 +514,7 @@ class PP:
 
 def pp_empty(n, c, h, w, device):
     px = _hip.lib().srhip_pp_plane_pixels(n, h, w)
-    return PP(torch.zeros(2, px, c, device=device, dtype=torch.bfloat16), n, c, h, w)
+    return PP(torch.zeros(px, 2 * c, device=device, dtype=torch.bfloat16), n, c, h, w)
 
 
 def pp_from_f32(x, out=None):
@@ -528,7 +528,7 @@ def pp_from_f32(x, out=None):
 
 
 def pp_to_f32(pp):
-    out = torch.empty(pp.n, pp.c, pp.h, pp.w, device=pp.buf.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    out = torch.empty(pp.n, pp.h, pp.w, pp.c, device=pp.buf.device, dtype=torch.float32).permute(0, 3, 1, 2)
     _hip.check(_hip.lib().srhip_pp_to_f32(_p(pp.buf), _p(out), pp.n, pp.h, pp.w, pp.c, pp.c, _stream()), 'pp_to_f32')
     return out
 
@@ -548,7 +548,7 @@ def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
         _require_gpu(x, 'conv2d_fwd_pp')
         x = nhwc(x)
     dev = x.buf.device if xpp else x.device
-    y = out_pp if out_pp is not None else torch.empty(n, cout, h, wd, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    y = out_pp if out_pp is not None else torch.empty(n, h, wd, cout, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
     flags = 0
     b = None
     if bias is not None:
@@ -577,7 +577,7 @@ def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=No
         _require_gpu(dy, 'conv2d_dgrad_pp')
         dy = nhwc(dy)
     dev = dy.buf.device if ypp else dy.device
-    dx = out_pp if out_pp is not None else torch.empty(n, cin, h, wd, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+    dx = out_pp if out_pp is not None else torch.empty(n, h, wd, cin, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
     if residual is not None:
         residual = nhwc(residual)
     _hip.check(_hip.lib().srhip_conv2d_dgrad_pp(ctypes.c_void_p(dy.data_ptr()), int(ypp), _p(packed_weight(w, 1)), ctypes.c_void_p(dx.data_ptr()),
@@ -615,6 +615,122 @@ def conv2d_wgrad_pp_raw(items, accumulate=True, on_stream=None):
                                         cout if xpp else cin, st), 'conv2d_wgrad_pp')
 
 
+class _PlanePool:
+    """Padded-plane buffers by geometry.  The kernels never write a buffer's pad / guard rows, so a buffer is zeroed once, when it
+    is created, and handed out again for any tensor of its geometry.  A released buffer carries events of the streams that may
+    still be reading it; get() takes the OLDEST released buffer whose events have completed and, when none has, a NEW buffer rather
+    than a wait -- a wait would put the main stream behind the weight-gradient stream's last launch (the overlap the step lives on)."""
+
+    def __init__(self):
+        self.free = {}              # key -> [(PP, [events])], oldest first
+        self.created = 0
+
+    def get(self, n, c, h, w, device):
+        key = (n, c, h, w, device.index)
+        q = self.free.get(key)
+        capturing = _state.capturing or torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # a stream capture: buffers the capture creates live in the graph's private pool and must not leave it, buffers from
+            # outside must not be queried (event queries are illegal while capturing): keep the two populations apart
+            key = key + ('capture',)
+            q = self.free.get(key)
+        if q:
+            for i, (pp, evs) in enumerate(q):
+                if capturing or all(ev.query() for ev in evs):
+                    del q[i]
+                    return pp
+        self.created += 1
+        return pp_empty(n, c, h, w, device)
+
+    def put(self, pp, streams=()):
+        capturing = _state.capturing or torch.cuda.is_current_stream_capturing()
+        evs = [] if capturing else [s.record_event() for s in streams]
+        key = (pp.n, pp.c, pp.h, pp.w, pp.buf.device.index) + (('capture',) if capturing else ())
+        self.free.setdefault(key, []).append((pp, evs))
+
+
+plane_pool = _PlanePool()
+_PP_RAB = os.environ.get('SRHIP_PP_RAB', '1') == '1'          # A/B knob: 0 = the RAB keeps t / dt as fp32 tensors (rounds 1-4)
+
+
+def rab_planes_ok(x, w1, w2):
+    """The RAB keeps its two 256-channel tensors as padded planes: split-bf16 arithmetic, 64 -> Cmid -> 64 with both 3x3 convs and
+    both weight gradients served on planes."""
+    if not (_PP_RAB and x.is_cuda and get_conv_math() == 'bf16x3'):
+        return False
+    n, c, h, w = x.shape
+    cm = w1.shape[0]
+    lib = _hip.lib()
+    return (tuple(w1.shape[2:]) == (3, 3) and tuple(w2.shape[2:]) == (3, 3) and w2.shape[0] == c and w2.shape[1] == cm
+            and bool(lib.srhip_conv2d_pp_ok(n, h, w, c, cm)) and bool(lib.srhip_conv2d_pp_ok(n, h, w, cm, c))
+            and (lib.srhip_conv2d_wgrad_pp_ok(n, h, w, c, cm) & 4) and (lib.srhip_conv2d_wgrad_pp_ok(n, h, w, cm, c) & 4))
+
+
+def _to_planes(t, device):
+    """fp32 NHWC operand of a weight gradient -> a pooled padded-plane copy (launched on the current stream)."""
+    n, c, h, w = t.shape
+    pp = plane_pool.get(n, c, h, w, device)
+    return pp_from_f32(t, out=pp)
+
+
+def _launch_wgrad_pp(items, side):
+    """items: [(x, dy, gw, gb, release)] of one shape: fp32 operands are converted to planes and the flat kernel runs, all on `side`
+    (None: the current stream); pooled buffers go back to the pool with an event of that stream."""
+    main = torch.cuda.current_stream()
+    run_on = side if side is not None else main
+    with torch.cuda.stream(run_on):
+        conv = []
+        launch = []
+        for x, dy, gw, gb, release in items:
+            xo, dyo = x, dy
+            if not isinstance(x, PP):
+                xo = _to_planes(x, gw.device)
+                conv.append(xo)
+            if not isinstance(dy, PP):
+                dyo = _to_planes(dy, gw.device)
+                conv.append(dyo)
+            launch.append((xo, dyo, gw, gb))
+        conv2d_wgrad_pp_raw(launch, accumulate=True, on_stream=side)
+        for pp in conv:
+            plane_pool.put(pp, (run_on,))
+        for x, dy, gw, gb, release in items:
+            for pp in release:
+                plane_pool.put(pp, (run_on,) if side is None else (run_on, main))
+    if side is not None:
+        for x, dy, gw, gb, release in items:
+            for t in (x, dy):
+                if not isinstance(t, PP):
+                    t.record_stream(side)
+            if not isinstance(dy, PP):
+                _hold_for_side(side, dy)
+
+
+def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
+    """Weight (+ bias) gradient of a 3x3 stride-1 pad-1 conv whose 256-channel operand is a PP (the other fp32 NHWC), accumulated into
+    the parameters' gradient slots by the flat kernel -- in pairs on the weight-gradient stream like wgrad_for_params.  `release`:
+    pooled PP buffers that go back to the pool once the launch is enqueued.  Returns False when direct accumulation is not possible
+    (the caller converts and takes the fp32 path)."""
+    gw = _grad_slot(w)
+    gb = _grad_slot(b) if (want_b and b is not None) else None
+    if gw is None or (want_b and b is not None and gb is None):
+        return False
+    side = _state.wgrad_stream
+    item = (x, dy, gw, gb, tuple(release))
+    if side is None:
+        _launch_wgrad_pp([item], None)
+        return True
+    if _state.wgrad_group > 1:
+        key = ('pp', tuple(x.shape), w.shape[0], gb is not None)
+        q = _state.pending.setdefault(key, [])
+        q.append(item + (_stream().value,))
+        if len(q) >= 2:
+            _flush_key(key)
+        return True
+    _fork_side(side)
+    _launch_wgrad_pp([item], side)
+    return True
+
+
 _WGRAD_DEFER = os.environ.get('SRHIP_WGRAD_DEFER', '0') == '1'     # experiment: hold every groupable weight gradient until a flush point
 _WGRAD_FLUSH_GROUP = int(os.environ.get('SRHIP_WGRAD_FLUSH_GROUP', '0'))   # convolutions per launch at a flush (0: the step's group size)
 
@@ -624,6 +740,10 @@ def _flush_key(key):
     if not items:
         return
     side = _state.wgrad_stream
+    if key[0] == 'pp':
+        _fork_side(side, [it[5] for it in items])
+        _launch_wgrad_pp([it[:5] for it in items], side)
+        return
     _fork_side(side, [it[6] for it in items])
     items = [it[:6] for it in items]
     per = max(1, _WGRAD_FLUSH_GROUP or _state.wgrad_group)
@@ -1110,6 +1230,22 @@ class _RabBlock(Function):
     def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
+        ctx.t_pp = None
+        if rab_planes_ok(x, w1, w2):
+            # round 5: t stays in padded split-bf16 planes between the block's own kernels (conv1's epilogue writes them, conv2 reads
+            # them without its in-place split, the backward's activation mask and weight gradient read them again)
+            n, _, h, wd = x.shape
+            t_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
+            conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=t_pp)
+            if pool_epilogue_ok(x, w2):
+                u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2, pool=True)
+            else:
+                u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2), None
+            out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
+            ctx.t_pp = t_pp
+            ctx.save_for_backward(x, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved)
+            ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
+            return out
         t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
         if pool_epilogue_ok(t, w2):                      # conv2 leaves the CLAM pooling partials of u behind (its epilogue, when the patch walk takes it)
             u, pool = conv2d_fwd_pool_raw(t, w2, b2)
@@ -1122,6 +1258,8 @@ class _RabBlock(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.t_pp is not None:
+            return _RabBlock._backward_planes(ctx, g)
         x, t, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
         g = nhwc(g)
         skip = _skip_param_grads()
@@ -1135,11 +1273,52 @@ class _RabBlock(Function):
             dw1, db1 = wgrad_for_params(w1, b1, x, dt, 1, 1, ctx.has_b[0])
         return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
 
+    @staticmethod
+    def _backward_planes(ctx, g):
+        """The backward with t and dt as padded planes: conv2's dgrad reads the mask from t's hi plane and writes dt as planes, conv1's
+        dgrad reads them without its split, both weight gradients run on the flat 8-wave kernel (the 64-channel operands x / du are
+        converted on the weight-gradient stream)."""
+        x, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
+        t_pp, ctx.t_pp = ctx.t_pp, None
+        g = nhwc(g)
+        skip = _skip_param_grads()
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_b[2], skip)
+        n, _, h, wd = x.shape
+        dt_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
+        conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=dt_pp)          # * LeakyReLU'(t), planes out
+        dw2 = db2 = dw1 = db1 = None
+        main = torch.cuda.current_stream()
+        t_done = dt_done = False
+        if not skip:
+            t_done = wgrad_pp_for_params(w2, b2, t_pp, du, ctx.has_b[1], release=(t_pp,))
+            if not t_done:                                # autograd wants the gradients returned: the fp32 path on converted operands
+                dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du, 1, 1, ctx.has_b[1])
+        dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g) if ctx.needs_input_grad[0] else None   # + skip gradient
+        if not skip:
+            dt_done = wgrad_pp_for_params(w1, b1, x, dt_pp, ctx.has_b[0], release=(dt_pp,))
+            if not dt_done:
+                dw1, db1 = wgrad_for_params(w1, b1, x, pp_to_f32(dt_pp), 1, 1, ctx.has_b[0])
+        if not t_done:
+            plane_pool.put(t_pp, (main,))
+        if not dt_done:
+            plane_pool.put(dt_pp, (main,))
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
+
 
 def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
     if _tail_eval_ok(x):                                 # inference: three conv-sized launches + the pooling partials per block
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
+        if rab_planes_ok(x, w1, w2):
+            n, _, h, wd = x.shape
+            t_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
+            conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=t_pp)
+            if pool_epilogue_ok(x, w2):
+                u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2, pool=True)
+            else:
+                u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2), None
+            plane_pool.put(t_pp, (torch.cuda.current_stream(),))
+            return _tail_forward_eval(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
         t = conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
         if pool_epilogue_ok(t, w2):
             u, pool = conv2d_fwd_pool_raw(t, w2, b2)

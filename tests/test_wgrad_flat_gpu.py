@@ -21,15 +21,19 @@ def test_padded_planes_round_trip_and_zero_padding():
     pp = ops.pp_from_f32(x)
     back = ops.pp_to_f32(pp)
     assert _rel(back, x.cpu()) < 2 ** -15                                   # hi + lo carries 16 significand bits
-    hi = pp.buf[0].float()
+    planes = pp.buf.view(-1, 8, 2, 8).float()                               # [row][octet][hi | lo][8 channels]
+    hi = planes[:, :, 0, :].reshape(-1, 64)
+    lo = planes[:, :, 1, :].reshape(-1, 64)
     guard = __import__('sradsgan_amd')._hip.lib().srhip_pp_guard(7)
     grid = hi[guard:guard + 3 * 6 * 8].view(3, 6, 8, 64)
     assert float(grid[:, 5].abs().max()) == 0.0 and float(grid[:, :, 7].abs().max()) == 0.0    # pad row / pad column
     assert float(hi[:guard].abs().max()) == 0.0 and float(hi[guard + 3 * 6 * 8:].abs().max()) == 0.0
+    assert float(lo[:guard].abs().max()) == 0.0 and float(lo[guard + 3 * 6 * 8:].abs().max()) == 0.0
     assert torch.equal(grid[:, :5, :7].permute(0, 3, 1, 2), x.to(torch.bfloat16).float())     # hi = round-to-nearest bf16
     # a buffer is reusable: converting another tensor of the same geometry leaves the padding untouched
     ops.pp_from_f32(-x, out=pp)
-    assert float(pp.buf[0][guard:guard + 144].view(3, 6, 8, 64)[:, 5].float().abs().max()) == 0.0
+    hi2 = pp.buf.view(-1, 8, 2, 8)[:, :, 0, :].reshape(-1, 64).float()
+    assert float(hi2[guard:guard + 144].view(3, 6, 8, 64)[:, 5].abs().max()) == 0.0
 
 
 CASES = [(2, 64, 23, 37, 128), (1, 128, 54, 54, 64), (2, 256, 9, 20, 64), (2, 64, 17, 16, 256), (1, 64, 23, 23, 128),
