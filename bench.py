@@ -254,7 +254,7 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     out = []
     kf = {'fp32': 'fast_conv_dma_kernel<128,128,bias+lrelu,fp32>', 'bf16x3': 'conv_patch_pers_kernel<128,bias+lrelu> (persistent tile walk)',
           'half': 'conv_patch_pers_kernel<128,run-time epilogue,fp16 single product>'}[math]
-    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>',
+    kw = {'fp32': 'fast_wgrad_dma_kernel<128,64,fp32>', 'bf16x3': 'wgrad_rowtap_kernel<128,64>',   # (bf16x3: replaced below by the flat kernel where the RAB runs it)
           'half': 'wgrad_rowtap_kernel<128,64,bf16 single product>'}[math]
     # The step launches the weight gradients of consecutive RABs in pairs (srhip_conv2d_wgrad_multi): the
     # dominant weight-gradient launch therefore processes TWO convolutions, and `roofline_wgrad` times exactly that launch
@@ -269,6 +269,25 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     single_wgrad = lambda: ops.conv2d_wgrad_raw(x, dy, (256, 64, 3, 3), 1, 1, True)
     wgrad_fn = (lambda: ops.conv2d_wgrad_multi_raw(items)) if group > 1 else single_wgrad
     kw_label = (kw + ' x%d convolutions per launch + %d reduces' % (group, group)) if group > 1 else (kw + ' + reduce')
+    wgrad_extra = {}
+    if math == 'bf16x3' and group == 2 and ops.rab_planes_ok(x, w, torch.empty(64, 256, 3, 3, device='meta')):
+        # Round 5: inside the RAB the step keeps dy (the 256-channel gradient, written by conv2's dgrad epilogue) as padded
+        # split-bf16 planes and launches the pair on the flat 8-wave kernel (csrc/conv_wgrad_flat.hip); the 64-channel operand x is
+        # converted by a small pass on the weight-gradient stream.  Timed here: exactly that -- two pp_from_f32 passes of x + the
+        # pair launch + its reduce --, with the pair launch alone (operands already planes) next to it.
+        ppy = [ops.pp_from_f32(d) for d in (dy, dy2)]
+        ppx = [ops.pp_empty(batch, 64, LR_SIDE, LR_SIDE, device) for _ in range(2)]
+        pitems = [(ppx[i], ppy[i], gw[i], gb[i]) for i in range(2)]
+
+        def wgrad_pp():
+            ops.pp_from_f32(x, out=ppx[0])
+            ops.pp_from_f32(x2, out=ppx[1])
+            ops.conv2d_wgrad_pp_raw(pitems)
+        wgrad_fn = wgrad_pp
+        kw_label = ('wgrad_flat8_kernel<dy planes 256 ch, x planes 64 ch> x2 convolutions per launch + reduce + the two pp_from_f32 passes of x')
+        wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_pp_raw(pitems), 200), 4)
+        wgrad_extra['rowtap_pair_launch_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_multi_raw(items), 200), 4)
+        single_wgrad = lambda: ops.conv2d_wgrad_pp_raw(pitems[:1])
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
             ('wgrad', kw_label + ': 3x3 64->256 @54x54 wgrad (RAB conv1)', wgrad_fn)):
@@ -328,6 +347,11 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         rec['launches_timed'] = n
         rec['achieved'] = round(flops / (sus * 1e-3) / 1e12, 2)
         rec['frac'] = round(rec['achieved'] / peak, 4)
+        if key == 'wgrad':
+            for k2, v2 in wgrad_extra.items():
+                rec[k2] = v2
+                if k2 == 'pair_launch_alone_ms':
+                    rec['pair_launch_alone_frac'] = round(flops / (v2 * 1e-3) / 1e12 / peak, 4)
         if key == 'wgrad' and group > 1 and with_single:         # (not under the profiler: keeps its per-kernel averages to the grouped launch)
             one = _time_launches(single_wgrad, 200)
             rec['convolutions_per_launch'] = group

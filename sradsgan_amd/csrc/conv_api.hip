@@ -190,6 +190,10 @@ int srhip_debug_set(int key, int value) {
     g_flat_abl = value;
     return SRHIP_OK;
   }
+  if (key == 14) {
+    g_flat_f32_k8 = value;
+    return SRHIP_OK;
+  }
   return SRHIP_ERR_ARG;
 }
 

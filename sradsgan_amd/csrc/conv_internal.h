@@ -94,6 +94,7 @@ int flat_wgrad(int nprob, const void* const* x, const void* const* dy, int x_pp,
                void* workspace, size_t workspace_bytes, int n, int h, int w, int cin, int cout, int ldf, void* stream);
 extern int g_flat_blocks;
 extern int g_flat_abl;
+extern int g_flat_f32_k8;
 
 // column sums (elementwise.hip), used for the bias gradient on the generic path
 size_t colsum_workspace_bytes(long rows, int c);

@@ -428,7 +428,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void w
 // Bias gradient: the block whose tile_n == chunk % ntn sums that chunk's dy rows (each wave the pieces it fetched): the ntn blocks
 // that share a split see the same chunks, so every chunk is summed once and the work is spread evenly; bias_partial has
 // nsplit * ntn rows.
-template <int CFG, int ABL = 0>
+// F32: the 64-channel operand (x in CFG 1, dy in CFG 2) is an fp32 NHWC tensor (row stride g.ldf), fetched as it lies and split IN PLACE by
+// the wave that fetched it, one chunk ahead of its first reader, inside the load phase (the 4-wave form's image: 256-byte rows,
+// 16-byte granule = [4 hi | 4 lo], odd rows [lo | hi], 128-byte halves swapped when (row >> 1) & 1).  Saves the stand-alone pp_from_f32
+// pass (24 MB read + 24 MB written per operand) the step would otherwise run for the block input x and the tail's gradient du.
+template <int CFG, int ABL = 0, int F32 = 0>
 __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch bt) {
   static_assert(CFG == 1 || CFG == 2, "two tile shapes");
   constexpr int TM = 2, TN = 3;
@@ -479,8 +483,8 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
   const int nk = max(c_end - c_begin, 0);
   const int shiftB = (kh - 1) * g.Wp - 1;
 
-  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dyp), 0, g.pp_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xp), 0, g.x_pp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dyp), 0, (F32 && CFG == 2) ? g.f32_bytes : g.pp_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xp), 0, (F32 && CFG == 1) ? g.f32_bytes : g.x_pp_bytes, 0x00020000);
   const unsigned y_plane = g.plane_bytes, x_plane = g.x_plane_bytes;      // byte distance hi -> lo
   // ---- the three DMA slots of this wave: (descriptor is x?, per-lane byte offset inside the operand, LDS destination inside a stage)
   unsigned d_voff[3], d_dst[3];
@@ -539,6 +543,30 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
 #pragma unroll
     for (int k = 0; k < 3; ++k) d_dst[k] = __builtin_amdgcn_readfirstlane(lds_base + d_dst[k]);
   }
+  // F32: slot 2 of waves 0-4 (CFG 1: x rows 4 w .. 4 w + 3 of 18) / 0-3 (CFG 2: dy rows 4 w .. of 16) is a piece of the fp32 operand:
+  // a per-lane walk of the padded grid (n, h, w) -> pixel of the UNPADDED tensor; a pad position is an out-of-range lane
+  const bool f_wave = F32 && wave < (CFG == 1 ? 5 : 4);
+  int f_n = 0, f_h = 0, f_w = 0, f_pix = 0;
+  unsigned f_choff = 0;
+  bool f_live = false;
+  if (F32) {
+    const int r = 4 * wave + (lane >> 4);                    // image row
+    const int pcq = lane & 15;
+    const int cq = pcq ^ (((r >> 1) & 1) << 3);              // logical 4-channel granule
+    const int ch = (CFG == 1 ? ci_base : m0) + cq * 4;
+    const int fC = CFG == 1 ? g.C : g.K;
+    f_live = f_wave && ch < fC && r < (CFG == 1 ? 18 : 16);
+    f_choff = (unsigned)ch * 4u;
+    const int per = g.Hp * g.Wp;
+    const long q = (long)c_begin * 16 + (CFG == 1 ? shiftB : 0) + r + per;   // (one image is added so that the division sees q >= 0)
+    const int n1 = (int)(q / per);
+    const int rem = (int)(q - (long)n1 * per);
+    f_n = n1 - 1;
+    f_h = rem / g.Wp;
+    f_w = rem - f_h * g.Wp;
+    f_pix = (f_n * g.H + f_h) * g.W + f_w;
+    if (f_wave) d_dst[2] = __builtin_amdgcn_readfirstlane(lds_base + (CFG == 1 ? A_B : 0) + wave * 1024);
+  }
   auto dma_s = [&](unsigned voff, unsigned soff, __amdgpu_buffer_rsrc_t r, unsigned dst) {
     if (ABL & 2) voff = F_OOB;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(dst) : "memory");
@@ -552,6 +580,25 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
     for (int k = 0; k < 3; ++k) {
       const bool isx = d_isx[k];                             // wave-uniform
       const unsigned dst = d_dst[k] == lds_base + SCRATCH ? d_dst[k] : d_dst[k] + stage * STAGE_B;
+      if (F32 && k == 2 && f_wave) {                         // the fp32 operand's piece: per-lane pixel, no scalar offset
+        const bool ok = live && f_live && (unsigned)f_n < (unsigned)g.N && f_h < g.H && f_w < g.W;
+        const unsigned vo = ok ? (unsigned)f_pix * (unsigned)g.ldf * 4u + f_choff : F_OOB;
+        if (CFG == 1) dma_s(vo, 0u, rs_x, dst);
+        else dma_s(vo, 0u, rs_y, dst);
+        f_w += 16;
+        f_pix += 16;
+        while (f_w >= g.Wp) {
+          f_w -= g.Wp;
+          f_pix -= g.Wp;
+          if (++f_h == g.Hp) {
+            f_h = 0;
+            ++f_n;
+          } else {
+            f_pix += g.W;
+          }
+        }
+        continue;
+      }
       if (isx) dma_s(live ? d_voff[k] : F_OOB, live ? so_x : 0u, rs_x, dst);
       else dma_s(live ? d_voff[k] : F_OOB, live ? so_y : 0u, rs_y, dst);
     }
@@ -563,18 +610,22 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
   const int li = lane & 15, g1 = (lane >> 4) & 1, khalf = lane >> 5, l31 = lane & 31;
   const int rq = li >> 2, q4 = li & 3;
   unsigned a_hi[TM], b_hi[TN];
-  constexpr int A_LO = CFG == 1 ? 16 * 256 : 16 * 128, B_LO = CFG == 1 ? 18 * 128 : 18 * 256, A_R4 = CFG == 1 ? 1024 : 512, B_R4 = CFG == 1 ? 512 : 1024;
+  constexpr int A_LO = CFG == 1 ? 16 * 256 : 16 * 128, B_LO = CFG == 1 ? 18 * 128 : 18 * 256;          // hi -> lo image of a plane operand
+  constexpr int A_R4 = (CFG == 1 || F32) ? 1024 : 512, B_R4 = (CFG == 1 && !F32) ? 512 : 1024;     // + 4 pixel rows
+  constexpr bool A_F32 = F32 && CFG == 2, B_F32 = F32 && CFG == 1;
   {
     const int r = 8 * khalf + rq;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       if (CFG == 1) a_hi[t] = grp * 8192 + r * 256 + (((wm * 2 + t) ^ (r & 3)) << 6) + 32 * g1 + 8 * q4;
+      else if (F32) a_hi[t] = r * 256 + (((t * 8 + 4 * g1 + q4) ^ (((r >> 1) & 1) << 3)) << 4) + 8 * (r & 1);
       else a_hi[t] = r * 128 + ((t ^ ((r >> 1) & 1)) << 6) + 32 * g1 + 8 * q4;
     }
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
       const int s = r + u;
-      if (CFG == 1) b_hi[u] = A_B + s * 128 + ((wn ^ ((s >> 1) & 1)) << 6) + 32 * g1 + 8 * q4;
+      if (CFG == 1 && F32) b_hi[u] = A_B + s * 256 + (((wn * 8 + 4 * g1 + q4) ^ (((s >> 1) & 1) << 3)) << 4) + 8 * (s & 1);
+      else if (CFG == 1) b_hi[u] = A_B + s * 128 + ((wn ^ ((s >> 1) & 1)) << 6) + 32 * g1 + 8 * q4;
       else b_hi[u] = A_B + grp * 9216 + s * 256 + ((wn ^ (s & 3)) << 6) + 32 * g1 + 8 * q4;
     }
   }
@@ -599,11 +650,44 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
   const bool bias_wave = CFG == 1 || wave < 4;               // waves that fetch dy pieces
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+  // F32: in-place split of this wave's fp32 piece of the stage (+ the bias column sums from the raw dy values, CFG 2)
+  auto convert_load = [&](int stage) {                       // this wave's raw fp32 granule (waves without an fp32 piece: nothing)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f_wave) v = __builtin_bit_cast(float4, *reinterpret_cast<const u32x4*>(lds + stage * STAGE_B + (CFG == 1 ? A_B : 0) + wave * 1024 + lane * 16));
+    return v;
+  };
+  auto convert_store = [&](int stage, const float4& v, bool sum_bias) {
+    if (!f_wave) return;
+    u32x4* slot = reinterpret_cast<u32x4*>(lds + stage * STAGE_B + (CFG == 1 ? A_B : 0) + wave * 1024 + lane * 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
+    const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
+    const bf16x2_t l01 = {(__bf16)(v.x - __uint_as_float(uh01 << 16)), (__bf16)(v.y - __uint_as_float(uh01 & 0xffff0000u))};
+    const bf16x2_t l23 = {(__bf16)(v.z - __uint_as_float(uh23 << 16)), (__bf16)(v.w - __uint_as_float(uh23 & 0xffff0000u))};
+    const unsigned ul01 = __builtin_bit_cast(unsigned, l01), ul23 = __builtin_bit_cast(unsigned, l23);
+    const bool odd = (lane >> 4) & 1;                        // image row parity (pieces start at multiples of 4 rows)
+    u32x4 o;
+    o.x = odd ? ul01 : uh01;
+    o.y = odd ? ul23 : uh23;
+    o.z = odd ? uh01 : ul01;
+    o.w = odd ? uh23 : ul23;
+    *slot = o;
+    if (CFG == 2 && sum_bias) {
+      bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
+    }
+  };
+  auto convert = [&](int stage, bool sum_bias) { convert_store(stage, convert_load(stage), sum_bias); };
+  auto bias_chunk = [&](int kc) { return want_bias && (c_begin + kc) % ntn == tile_n; };
+
   // ---- prologue: three chunks in flight, chunk 0 landed for everybody, group 1 one barrier behind
   issue(0, 0);
   issue(1, 1);
   issue(2, 2);
   wait_vmcnt<6>();
+  if (F32) {
+    convert(0, bias_chunk(0));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (grp == 1) {
@@ -612,20 +696,25 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
   }
   for (int kc = 0; kc < nk; ++kc) {
     // ---- load phase of chunk kc (the other group multiplies)
+    float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (F32) {                                              // chunk kc + 1's own pieces have landed (kc + 2 may be in flight): fetch the raw fp32
+      wait_vmcnt<3>();                                      // granule FIRST, so that its LDS latency hides under the DMA issue and the
+      if (kc + 1 < nk) raw = convert_load((kc + 1) & 3);    // fragment reads below; it is split and written back at the end of the phase
+    }
     issue(kc + 3, (kc + 3) & 3);
     const unsigned sb = lds_base + (kc & 3) * STAGE_B;
     bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       ah[t] = frag(sb + a_hi[t], A_R4);
-      al[t] = frag(sb + a_hi[t] + A_LO, A_R4);
+      al[t] = frag(sb + (A_F32 ? a_hi[t] ^ 8u : a_hi[t] + A_LO), A_R4);
     }
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
       bh[u] = frag(sb + b_hi[u], B_R4);
-      bl[u] = frag(sb + b_hi[u] + B_LO, B_R4);
+      bl[u] = frag(sb + (B_F32 ? b_hi[u] ^ 8u : b_hi[u] + B_LO), B_R4);
     }
-    if (want_bias && bias_wave && (c_begin + kc) % ntn == tile_n) {     // this block's share of the bias gradient: the dy pieces this wave fetched
+    if (!A_F32 && want_bias && bias_wave && (c_begin + kc) % ntn == tile_n) {     // this block's share of the bias gradient: the dy pieces this wave fetched
 #pragma unroll
       for (int k = 0; k < (CFG == 1 ? 2 : 1); ++k) {
         const unsigned off = (CFG == 1 ? grp * 8192 + (4 * k + w4) * 1024 : wave * 1024) + lane * 16;
@@ -638,7 +727,11 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
         }
       }
     }
-    if (grp == 1) wait_vmcnt<6>();                          // own DMAs of chunk kc + 1 landed before the barrier that publishes it
+    if (F32) {                                              // one barrier (group 0) / two (group 1) ahead of the split granule's first reader
+      if (kc + 1 < nk) convert_store((kc + 1) & 3, raw, bias_chunk(kc + 1));
+    } else if (grp == 1) {
+      wait_vmcnt<6>();                                      // own DMAs of chunk kc + 1 landed before the barrier that publishes it
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -659,7 +752,7 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
 #pragma unroll
       for (int u = 0; u < TN; ++u) asm volatile("" ::"v"(bh[u]), "v"(bl[u]));
     }
-    if (grp == 0) wait_vmcnt<6>();
+    if (!F32 && grp == 0) wait_vmcnt<6>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -711,6 +804,15 @@ __global__ __launch_bounds__(512) void wgrad_flat8_kernel(FlatGeom g, FlatBatch 
           for (int rl = 0; rl < 4; ++rl) {
             const int pgi = (((lgq >> 2) ^ rl) << 2) | (lgq & 3);
             s += bl_[((gq * 4 + w) * 64 + rl * 16 + pgi) * 8 + e];
+          }
+      } else if (F32) {                                      // waves 0-3: rows 4 w + rl of the fp32 image, 4-channel granules
+        const int cq = tid >> 2, e4 = tid & 3;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int rl = 0; rl < 4; ++rl) {
+            const int pcq = cq ^ ((((4 * w + rl) >> 1) & 1) << 3);
+            s += bl_[(w * 64 + rl * 16 + pcq) * 8 + e4];
           }
       } else {                                               // waves 0-3: pieces (plane, 8-row half); rows 8 (w & 1) + rl
         const int lgq = tid >> 3;
@@ -772,6 +874,7 @@ __global__ __launch_bounds__(256) void pp_to_f32_kernel(const __bf16* __restrict
 // ---- host side -------------------------------------------------------------------------------------------------------------- //
 extern int g_conv_math;
 int g_flat_abl = 0;         // srhip_debug_set(13, bits): timing-only ablations of wgrad_flat_kernel
+int g_flat_f32_k8 = 1;      // srhip_debug_set(14, v): 0 = one fp32 operand always takes the 4-wave kernel (1: the 8-wave kernel where its tile fits)
 int g_flat_blocks = 768;      // srhip_debug_set(12, n): split-K block target of wgrad_flat_kernel
 bool launch_reduce4_shared(int nprob, const float* const* partial, const float* const* bias_partial, float* const* dw, float* const* db,
                            int nsplit, int cout, int cin, int khkw, int ktot, int accumulate, hipStream_t st, int nbias);
@@ -824,7 +927,8 @@ struct FlatPlan {
 };
 static FlatPlan flat_plan(int x_pp, int dy_pp, int cin, int cout, int nchunks, int nprob) {
   FlatPlan p;
-  p.kernel = (x_pp && dy_pp) ? 8 : 4;
+  const bool k8shape = (cout % 8 == 0 && cout >= 256 && cin % 64 == 0) || (cout == 64 && cin % 256 == 0);
+  p.kernel = ((x_pp && dy_pp) || (k8shape && g_flat_f32_k8)) ? 8 : 4;
   if (p.kernel == 8) {
     p.cfg = cout >= 256 ? 1 : 2;
     const int ncs = cin / (p.cfg == 1 ? 64 : 256);
@@ -875,6 +979,12 @@ int flat_wgrad(int nprob, const void* const* x, const void* const* dy, int x_pp,
     g.plane_bytes = (unsigned)(ppx * cout * 2L);               // dy
     g.pp_bytes = 2u * g.plane_bytes;
     g.f32_bytes = 0;
+    if (!(x_pp && dy_pp)) {
+      const int fC = dy_pp ? cin : cout;                        // channels of the fp32 operand
+      const long fb = ((long)n * h * w - 1) * (long)ldf * 4L + (long)fC * 4L;
+      SRHIP_REQUIRE(fb < (1L << 31) && ldf % 4 == 0 && ldf >= fC, "conv2d_wgrad_pp: fp32 operand >= 2 GiB or bad row stride");
+      g.f32_bytes = (unsigned)fb;
+    }
   } else {
     const int plC = p.cfg == 1 ? cout : cin, fC = p.cfg == 1 ? cin : cout;
     g.plane_bytes = (unsigned)(ppx * plC * 2L);
@@ -911,7 +1021,10 @@ int flat_wgrad(int nprob, const void* const* x, const void* const* dy, int x_pp,
   } else
     SRHIP_F8(1) SRHIP_F8(2) SRHIP_F8(4) SRHIP_F8(8) SRHIP_F8(3) SRHIP_F8(5) SRHIP_F8(6) SRHIP_F8(7) SRHIP_F8(15)
 #undef SRHIP_F8
-    if (cfg == 1) hipLaunchKernelGGL((wgrad_flat8_kernel<1>), dim3(blocks), dim3(512), 0, st, g, bt);
+    if (!(x_pp && dy_pp)) {
+      if (cfg == 1) hipLaunchKernelGGL((wgrad_flat8_kernel<1, 0, 1>), dim3(blocks), dim3(512), 0, st, g, bt);
+      else hipLaunchKernelGGL((wgrad_flat8_kernel<2, 0, 1>), dim3(blocks), dim3(512), 0, st, g, bt);
+    } else if (cfg == 1) hipLaunchKernelGGL((wgrad_flat8_kernel<1>), dim3(blocks), dim3(512), 0, st, g, bt);
     else hipLaunchKernelGGL((wgrad_flat8_kernel<2>), dim3(blocks), dim3(512), 0, st, g, bt);
   } else {
 #define SRHIP_FA(ABL_)                                                                                   \

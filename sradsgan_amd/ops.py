@@ -666,6 +666,9 @@ def rab_planes_ok(x, w1, w2):
             and (lib.srhip_conv2d_wgrad_pp_ok(n, h, w, c, cm) & 4) and (lib.srhip_conv2d_wgrad_pp_ok(n, h, w, cm, c) & 4))
 
 
+_WGRAD_PP_CONVERT = os.environ.get('SRHIP_WGRAD_PP_CONVERT', '1') == '1'   # 1 (default): a pp_from_f32 pass of the 64-channel operand on the weight-gradient stream (in-step +0.4 % over the kernel's own in-place split: profiles/r05_wgrad_flat.txt)
+
+
 def _to_planes(t, device):
     """fp32 NHWC operand of a weight gradient -> a pooled padded-plane copy (launched on the current stream)."""
     n, c, h, w = t.shape
@@ -683,12 +686,13 @@ def _launch_wgrad_pp(items, side):
         launch = []
         for x, dy, gw, gb, release in items:
             xo, dyo = x, dy
-            if not isinstance(x, PP):
-                xo = _to_planes(x, gw.device)
-                conv.append(xo)
-            if not isinstance(dy, PP):
-                dyo = _to_planes(dy, gw.device)
-                conv.append(dyo)
+            if _WGRAD_PP_CONVERT:                        # A/B knob: a stand-alone pp_from_f32 pass instead of the kernel's in-place split
+                if not isinstance(x, PP):
+                    xo = _to_planes(x, gw.device)
+                    conv.append(xo)
+                if not isinstance(dy, PP):
+                    dyo = _to_planes(dy, gw.device)
+                    conv.append(dyo)
             launch.append((xo, dyo, gw, gb))
         conv2d_wgrad_pp_raw(launch, accumulate=True, on_stream=side)
         for pp in conv:

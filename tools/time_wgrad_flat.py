@@ -40,7 +40,7 @@ for cin, cout in ((64, 256), (256, 64)):
     for fmt in ('one', 'both'):
         if fmt == 'one':
             items = [(xs[i], ppy[i], gw[i], gb[i]) if mask & 1 else (ppx[i], dys[i], gw[i], gb[i]) for i in range(2)]
-            blist = (768,)
+            blist = (768, 256)
         else:
             items = [(ppx[i], ppy[i], gw[i], gb[i]) for i in range(2)]
             blist = (256, 255, 240, 512)
