@@ -194,6 +194,14 @@ int srhip_debug_set(int key, int value) {
     g_flat_f32_k8 = value;
     return SRHIP_OK;
   }
+  if (key == 15) {
+    g_patch8 = value;
+    return SRHIP_OK;
+  }
+  if (key == 16) {
+    g_patch8_abl = value;
+    return SRHIP_OK;
+  }
   return SRHIP_ERR_ARG;
 }
 
@@ -394,7 +402,7 @@ int srhip_conv2d_wgrad_pp_ok(int n, int h, int w, int cin, int cout) {
 }
 int srhip_conv2d_pp_ok(int n, int h, int w, int cin, int cout) {
   if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || g_conv_math != 1) return 0;
-  if (cin % 32 != 0 || cout % 8 != 0 || cout < 64 || cin < 32) return 0;
+  if (cin % 32 != 0 || cout % 8 != 0 || cout < 64 || cin < 32 || cout > 512) return 0;      // (> 512: the 4-wave kernel keeps the bias vector in 2 KiB of LDS)
   const long px = pp_plane_pixels(n, h, w);
   return px * (cin > cout ? cin : cout) * 4L < (1L << 31) ? 1 : 0;
 }

@@ -161,4 +161,10 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
                       float* dst, const FastGeom& g, const PatchGeom& pg, int nbm, int nbn, bool wide, int prod, int eflags,
                       hipStream_t st);     // g.src_pp / g.dst_pp: src / dst (and, with dst_pp, actmask) point at padded planes
 
+// conv_patch8.hip: the 8-wave two-group patch kernel for >= 256 destination channels; -1 = not applicable
+int launch_patch8(const float* src, const float* wt, const float* bias, const float* actmask, float* dst, const FastGeom& g,
+                  const PatchGeom& pg, int nbm, int eflags, hipStream_t st);
+extern int g_patch8;
+extern int g_patch8_abl;
+
 }  // namespace srhip

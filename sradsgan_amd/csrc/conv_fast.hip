@@ -2574,6 +2574,10 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
       const int nbm = g.N * pg.tiles_h * pg.tiles_w;
       const bool wide = g.K >= 128;
       const int nbn = cdiv(g.K, wide ? 128 : 64);
+      if (wide && !residual) {                            // >= 256 destination channels: the 8-wave two-group kernel (conv_patch8.hip)
+        const int rc8 = launch_patch8(src, wt, bias, actmask, dst, g, pg, nbm, ef, st);
+        if (rc8 >= 0) return rc8;
+      }
       const int rc = launch_patch_pers(src, wt, bias, residual, actmask, dst, g, pg, nbm, nbn, wide, 0, ef, st);
       if (rc >= 0) return rc;
     }
@@ -2635,6 +2639,10 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
         patch_to_dma = (long)nbm * nbn >= 256;
       } else if ((long)nbm * nbn >= 256 || g_fast_cfg == -2) {
         const float* wsplit = w16;
+        if (!(g.flags & 0x400) && wide && prod == 0 && !residual && g_fast_cfg != 23) {   // >= 256 destination channels: the 8-wave two-group kernel
+          const int rc8 = launch_patch8(src, wt, bias, actmask, dst, g, pg, nbm, eflags, st);
+          if (rc8 >= 0) return rc8;
+        }
         if (!(g.flags & 0x400)) {                         // persistent tile walk (srhip_debug_set(5, -1): never)
           const int rc = launch_patch_pers(src, wt, bias, residual, actmask, dst, g, pg, nbm, nbn, wide, prod, eflags, st);
           if (rc >= 0) return rc;

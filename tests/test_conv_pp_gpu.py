@@ -97,3 +97,38 @@ def test_tiny_image_on_padded_planes_against_fp64():
         dt_pp = ops.conv2d_dgrad_pp_raw(_cl(du), w2p, actmask=t_pp, slope=0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV))
         assert rel(ops.pp_to_f32(dt_pp), dt64) < 2e-5
         assert rel(ops.conv2d_dgrad_pp_raw(dt_pp, w1p), dx64) < 3e-5
+
+
+@pytest.mark.parametrize('case', [(32, 64, 54, 54, 256), (16, 64, 54, 54, 256), (12, 64, 54, 54, 256), (16, 64, 40, 37, 256), (8, 64, 54, 54, 576),
+                                  (12, 128, 54, 54, 256), (4, 64, 108, 108, 256), (16, 32, 54, 54, 320)])
+def test_eight_wave_patch_kernel_is_bit_identical_to_the_four_wave_kernels(case):
+    """conv_patch8_kernel (csrc/conv_patch8.hip: one 8-wave block per CU, two wave groups one barrier apart, >= 256 destination
+    channels, >= one tile per CU) against conv_patch_pers_kernel (srhip_debug_set(15, 0)) on the same operands: forward with
+    bias + LeakyReLU and the data gradient with an activation mask, to fp32 tensors and to padded planes, several tiles per block,
+    ragged images, a channel count that does not fill the last 256-wide tile, 2 / 4 / 8 chunks."""
+    from sradsgan_amd import ops, _hip
+    n, cin, h, w, cout = case
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(sum(case) + 23)
+    x = _cl(torch.randn(n, cin, h, w, generator=g))
+    w1 = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV))
+    b1 = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    w2 = torch.nn.Parameter((torch.randn(cin, cout, 3, 3, generator=g) * 0.05).to(DEV))     # dgrad: cin -> cout channels
+    du = _cl(torch.randn(n, cin, h, w, generator=g))
+    with ops.conv_math('bf16x3'):
+        res = {}
+        for k8 in (0, 1):
+            lib.srhip_debug_set(15, k8)
+            try:
+                t = ops.conv2d_fwd_raw(x, w1, b1, 1, 1, 0.2)
+                dt = ops.conv2d_dgrad_raw(du, w2, tuple(t.shape), 1, 1, None, t, 0.2)
+                out = [t, dt]
+                if ops.conv2d_pp_ok(n, cin, h, w, cout):
+                    t_pp = ops.conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=ops.pp_empty(n, cout, h, w, DEV))
+                    dt_pp = ops.conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=ops.pp_empty(n, cout, h, w, DEV))
+                    out += [t_pp.buf, dt_pp.buf]
+                res[k8] = out
+            finally:
+                lib.srhip_debug_set(15, 0)
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)

@@ -5,7 +5,7 @@ rocprofv3) and MFMA-busy fraction.  Writes <dir>/summary.txt and <dir>/roofline_
 import csv, glob, json, os, re, sys, collections
 
 root = sys.argv[1]
-KEYS = {'fprop': ('conv_patch_kernel', 'conv_patch_pers_kernel', 'fast_conv_dma_kernel'), 'wgrad': ('fast_wgrad_dma_kernel', 'wgrad_rowtap_kernel', 'fast_wgrad_reduce_kernel', 'fast_wgrad_reduce4_kernel')}
+KEYS = {'fprop': ('conv_patch_kernel', 'conv_patch_pers_kernel', 'fast_conv_dma_kernel'), 'wgrad': ('fast_wgrad_dma_kernel', 'wgrad_rowtap_kernel', 'wgrad_flat8_kernel', 'wgrad_flat_kernel', 'pp_from_f32_kernel', 'fast_wgrad_reduce_kernel', 'fast_wgrad_reduce4_kernel')}
 out, lines = {}, []
 
 
@@ -32,12 +32,15 @@ for mode in ('fp32', 'bf16x3', 'half'):
         total = 0.0
         # a grouped weight-gradient launch is ONE main kernel + one reduce per convolution: weigh every kernel by its number of
         # dispatches relative to the main kernel's, so the figure stays "HBM bytes per launch of the dominant kernel"
-        main_calls = max([len(pmc[k].get('FETCH_SIZE', [])) for k in pmc if any(n in k for n in names) and 'reduce' not in k] or [0])
+        aux = lambda k: 'reduce' in k or 'pp_from_f32' in k          # kernels that ride beside the main launch (reduces, operand conversion passes)
+        main_calls = max([len(pmc[k].get('FETCH_SIZE', [])) for k in pmc if any(n in k for n in names) and not aux(k)] or [0])
         for k in sorted(pmc):
             if not any(n in k for n in names):
                 continue
             c = pmc[k]
-            weight = (len(c.get('FETCH_SIZE', [])) / main_calls) if (main_calls and 'reduce' in k) else 1.0
+            weight = (len(c.get('FETCH_SIZE', [])) / main_calls) if (main_calls and aux(k)) else 1.0
+            if not aux(k) and main_calls and len(c.get('FETCH_SIZE', [])) < main_calls // 2:
+                weight = 0.0                                         # a kernel timed only for comparison (e.g. the row-tap pair beside the flat kernel)
             avg = lambda name: (sum(c[name]) / len(c[name])) if c.get(name) else 0.0
             fetch, write = avg('FETCH_SIZE') * 1024 * 2, avg('WRITE_SIZE') * 1024
             calls, ns = stats.get(k, (0, 0.0))
