@@ -294,6 +294,13 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
                         const float* fc2, float* du, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
                         int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
                         void* stream);
+/* ABI 9: the same, and the final du also as padded split-bf16 planes (du_pp; NULL: not wanted): the RAB's conv2 data and weight
+ * gradient read it without a conversion pass */
+int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
+                        const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
+                        const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
+                        int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
+                        void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

@@ -439,7 +439,10 @@ __global__ void tail_bwd_ds_kernel(const float* __restrict__ dsp, float* __restr
 __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restrict__ davg,
                                     const float* __restrict__ dmax, const int* __restrict__ arg, int hw, long npix,
                                     int pix_blocks, const float* __restrict__ pw1, const float* __restrict__ pw2,
-                                    float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden, int accfc) {
+                                    float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden, int accfc,
+                                    unsigned* __restrict__ du_pp = nullptr, int wd = 0, int guard = 0) {
+  // du_pp (round 5): the final du also leaves as padded split-bf16 planes (csrc/conv_wgrad_flat.hip: pixel row of 64 * 4 bytes,
+  // per 8 channels 8 hi | 8 lo halves): the RAB's conv2 data gradient and weight gradient read it without a conversion pass
   if ((int)blockIdx.x >= pix_blocks) {
     const int i = ((int)blockIdx.x - pix_blocks) * blockDim.x + threadIdx.x;
     const int per = hidden * TC;
@@ -466,6 +469,18 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
   d.z += ga.z * inv + (am.z == p ? gm.z : 0.f);
   d.w += ga.w * inv + (am.w == p ? gm.w : 0.f);
   *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = d;
+  if (du_pp != nullptr) {
+    const int y = p / wd, x = p - y * wd;
+    const long row = guard + ((long)b * (hw / wd + 1) + y) * (wd + 1) + x;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h01 = {(__bf16)d.x, (__bf16)d.y}, h23 = {(__bf16)d.z, (__bf16)d.w};
+    const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
+    const bf16x2_t l01 = {(__bf16)(d.x - __uint_as_float(uh01 << 16)), (__bf16)(d.y - __uint_as_float(uh01 & 0xffff0000u))};
+    const bf16x2_t l23 = {(__bf16)(d.z - __uint_as_float(uh23 << 16)), (__bf16)(d.w - __uint_as_float(uh23 & 0xffff0000u))};
+    unsigned* o = du_pp + row * TC + (cq >> 1) * 8 + (cq & 1) * 2;       // dwords: octet * 8, hi half at +0 / +2, lo half at +4 / +6
+    *reinterpret_cast<uint2*>(o) = make_uint2(uh01, uh23);
+    *reinterpret_cast<uint2*>(o + 4) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+  }
 }
 
 // ---- B4b: backward of s = sigmoid(W2 relu(W1 avg) + W2 relu(W1 max)) for one image per block ------- //
@@ -977,6 +992,15 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
                         const float* fc2, float* du, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
                         int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
                         void* stream) {
+  return srhip_attn_tail_bwd_pp(dz, u, s, m, pooled, argc, avg, mx, argmax_hw, w7, fc1, fc2, du, nullptr, dw7, accumulate_dw7, dfc1, dfc2,
+                                accumulate_dfc, workspace, workspace_bytes, n, h, w, c, hidden, stream);
+}
+/* ABI 9: the same, and du also as padded split-bf16 planes in du_pp (NULL: not wanted) */
+int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
+                           const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
+                           const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
+                           int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
+                           void* stream) {
   SRHIP_REQUIRE(dz && u && s && m && pooled && argc && avg && mx && argmax_hw && w7 && fc1 && fc2 && du && dw7 && dfc1 && dfc2,
                 "attn_tail_bwd: null tensor");
   SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_bwd: C must be 64, hidden <= 16");
@@ -1008,8 +1032,9 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
                      w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
   const int pix_blocks = (int)cdiv(npix, 16), red_blocks = (int)cdiv(2 * hidden * TC, 256);
+  SRHIP_REQUIRE(!du_pp || (((uintptr_t)du_pp) & 15) == 0, "attn_tail_bwd: du_pp must be 16-byte aligned");
   hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(pix_blocks + red_blocks), dim3(256), 0, st, du, davg, dmax, argmax_hw, hw, npix, pix_blocks,
-                     pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc);
+                     pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc, static_cast<unsigned*>(du_pp), w, srhip_pp_guard(w));
   return check_launch("attn_tail_bwd");
 }
 

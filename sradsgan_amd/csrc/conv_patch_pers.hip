@@ -742,6 +742,8 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
       SRHIP_PPX(128, -1, 0, 0, 1, nullptr, 0u);
     }
     if (!g.src_pp) SRHIP_PPX(64, -1, 0, 0, 1, nullptr, 0u);
+    if (wide && eflags == SRHIP_EPI_ACTMASK) SRHIP_PPX(128, 32, 0, 1, 1, nullptr, 0u);     // conv2 dgrad from the tail's du planes
+    if (wide && eflags == (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) SRHIP_PPX(128, 3, 0, 1, 1, nullptr, 0u);   // conv1 fprop from x planes
     if (wide) SRHIP_PPX(128, -1, 0, 1, 1, nullptr, 0u);
     SRHIP_PPX(64, -1, 0, 1, 1, nullptr, 0u);
 #undef SRHIP_PPX

@@ -650,6 +650,9 @@ class _PlanePool:
 
 
 plane_pool = _PlanePool()
+if os.environ.get('SRHIP_FLAT_BLOCKS'):                        # experiment: blocks of the 8-wave weight-gradient kernel (default: one per CU)
+    _hip.lib().srhip_debug_set(12, int(os.environ['SRHIP_FLAT_BLOCKS']))
+_DU_PP = os.environ.get('SRHIP_DU_PP', '1') == '1'              # A/B knob: 0 = conv2's gradients read the fp32 du (split in the dgrad kernel, pp_from_f32 pass for the weight gradient)
 _PP_RAB = os.environ.get('SRHIP_PP_RAB', '1') == '1'          # A/B knob: 0 = the RAB keeps t / dt as fp32 tensors (rounds 1-4)
 
 
@@ -1133,8 +1136,9 @@ def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
     return out, (avg, mx, arg, s, pooled, argc, m)
 
 
-def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=False):
-    """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc)."""
+def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=False, du_pp=None):
+    """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc).  du_pp: a PP buffer that also receives du
+    as padded planes (fused path only; the caller checks `_TAIL_FUSED`)."""
     avg, mx, arg, s, pooled, argc, m = saved
     n, c, h, w = u.shape
     lib = _hip.lib()
@@ -1166,10 +1170,11 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
         return du, (None if direct else dfc1), (None if direct else dfc2), (None if g7 is not None else dw7), dwc, dbc
     # spatial half (7x7 conv, per-pixel gate), channel half (sigmoid -> shared MLP) and the arg-max fix-up: one call
     ws = torch.empty(lib.srhip_attn_tail_bwd_fused_workspace(n, h, w, hid) // 4, **f32)
-    _hip.check(lib.srhip_attn_tail_bwd(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
-                                       _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
-                                       _p(fc2_w.detach().contiguous()), _p(du), _p(dw7), int(g7 is not None), _p(dfc1), _p(dfc2),
-                                       int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd')
+    _hip.check(lib.srhip_attn_tail_bwd_pp(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
+                                          _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
+                                          _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
+                                          int(g7 is not None), _p(dfc1), _p(dfc2),
+                                          int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd')
     if g7 is not None:
         dw7 = None
     if direct:
@@ -1286,15 +1291,19 @@ class _RabBlock(Function):
         t_pp, ctx.t_pp = ctx.t_pp, None
         g = nhwc(g)
         skip = _skip_param_grads()
-        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_b[2], skip)
         n, _, h, wd = x.shape
+        # the tail's backward leaves du as fp32 (the gradient of the block's residual stream) AND as padded planes: conv2's data and
+        # weight gradient read the planes (no in-kernel split, no conversion pass)
+        du_pp = plane_pool.get(n, u.shape[1], h, wd, x.device) if (_TAIL_FUSED and _DU_PP) else None
+        du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_b[2], skip, du_pp)
         dt_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
-        conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=dt_pp)          # * LeakyReLU'(t), planes out
+        conv2d_dgrad_pp_raw(du_pp if du_pp is not None else du, w2, actmask=t_pp, slope=0.2, out_pp=dt_pp)   # * LeakyReLU'(t), planes out
         dw2 = db2 = dw1 = db1 = None
         main = torch.cuda.current_stream()
         t_done = dt_done = False
         if not skip:
-            t_done = wgrad_pp_for_params(w2, b2, t_pp, du, ctx.has_b[1], release=(t_pp,))
+            t_done = wgrad_pp_for_params(w2, b2, t_pp, du_pp if du_pp is not None else du, ctx.has_b[1],
+                                         release=(t_pp,) if du_pp is None else (t_pp, du_pp))
             if not t_done:                                # autograd wants the gradients returned: the fp32 path on converted operands
                 dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du, 1, 1, ctx.has_b[1])
         dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g) if ctx.needs_input_grad[0] else None   # + skip gradient
@@ -1304,6 +1313,8 @@ class _RabBlock(Function):
                 dw1, db1 = wgrad_for_params(w1, b1, x, pp_to_f32(dt_pp), 1, 1, ctx.has_b[0])
         if not t_done:
             plane_pool.put(t_pp, (main,))
+            if du_pp is not None:
+                plane_pool.put(du_pp, (main,))
         if not dt_done:
             plane_pool.put(dt_pp, (main,))
         return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc

@@ -32,7 +32,7 @@ def rel_err(a, b):
 ZERO_GRAD_KEYS = tuple('model.%d.bias' % i for i in (2, 5, 8, 11, 14, 19, 22)) + ('key_conv.bias',)
 
 
-def grad_score(hip_nets, ora_nets, floor=1e-2, verbose=False):
+def grad_score(hip_nets, ora_nets, floor=1e-2, verbose=False, kind=None):
     """max over parameter tensors of max|dg| / max(max|g_tensor|, floor * max|g_network|); returns
     (score, name of the worst tensor).  ZERO_GRAD_KEYS are skipped (see above).  The floor exists
     because D's gradients are differences of large real/fake terms: a tensor whose own gradient is
@@ -44,6 +44,11 @@ def grad_score(hip_nets, ora_nets, floor=1e-2, verbose=False):
             continue
         net_scale = max(float(g.abs().max()) for g in og.values())
         for k, p in hn.named_parameters():
+            nd = p.grad.dim() if p.grad is not None else 0
+            if kind == 'weights' and nd < 2:            # kind: 'weights' = tensors with >= 2 dimensions, 'vectors' = biases / BN scales / gammas
+                continue
+            if kind == 'vectors' and nd >= 2:
+                continue
             if k in og and p.grad is not None and not k.endswith(ZERO_GRAD_KEYS):
                 d = float((p.grad.detach().cpu().double() - og[k].double()).abs().max())
                 own = float(og[k].abs().max())
