@@ -285,8 +285,9 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
             ops.conv2d_wgrad_pp_raw(pitems)
         wgrad_fn = wgrad_pp
         kw_label = ('wgrad_flat8_kernel<dy planes 256 ch, x planes 64 ch> x2 convolutions per launch + reduce + the two pp_from_f32 passes of x')
-        wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_pp_raw(pitems), 200), 4)
-        wgrad_extra['rowtap_pair_launch_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_multi_raw(items), 200), 4)
+        if with_single:                                   # (not under the profiler: its per-kernel averages and byte counters then belong to the launch the step runs)
+            wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_pp_raw(pitems), 200), 4)
+            wgrad_extra['rowtap_pair_launch_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_multi_raw(items), 200), 4)
         single_wgrad = lambda: ops.conv2d_wgrad_pp_raw(pitems[:1])
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),

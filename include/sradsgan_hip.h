@@ -184,6 +184,11 @@ int srhip_pp_guard(int w);
  * partials as srhip_conv2d_fwd_pool.  dgrad: residual (fp32 destination only) is added; actmask (pp destination only) = the PP of
  * the LeakyReLU output that fed the forward conv: dx is multiplied by the activation's derivative. */
 int srhip_conv2d_pp_ok(int n, int h, int w, int cin, int cout);
+/* srhip_conv2d_fwd whose fp32 output also leaves as padded planes (the attention tail's 1x1 conv, sradsgan.py:262-274: the next RAB's
+ * input in both forms); *served = 0 when the kernel that took the launch has no second destination (the caller converts y). */
+int srhip_conv2d_fwd_dual(const float* x, const float* packed, const float* bias, const float* residual, const float* rowscale,
+                          const float* chanscale, float* y, void* y_pp, int* served, int n, int h, int w, int cin, int cout, int kh,
+                          int kw, int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, void* stream);
 int srhip_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const float* bias, void* y, int y_pp, float* pool, size_t pool_sec_bytes,
                         int* nseg_out, int n, int h, int w, int cin, int cout, float slope, int flags, void* stream);
 int srhip_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,

@@ -41,6 +41,7 @@ SIGNATURES = {
     'srhip_pp_from_f32': (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
     'srhip_pp_to_f32': (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
     'srhip_conv2d_pp_ok': (_i, [_i] * 5),
+    'srhip_conv2d_fwd_dual': (_i, [_vp] * 9 + [_i] * 12 + [_f, _i, _vp]),
     'srhip_conv2d_fwd_pp': (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp] + [_i] * 5 + [_f, _i, _vp]),
     'srhip_conv2d_dgrad_pp': (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _f] + [_i] * 5 + [_vp]),
     'srhip_conv2d_wgrad_pp_ok': (_i, [_i] * 5),

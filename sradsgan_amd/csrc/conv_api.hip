@@ -267,6 +267,23 @@ int srhip_conv2d_fwd(const float* x, const float* packed, const float* bias, con
                            ldr, slope, flags, stream);
 }
 
+/* ABI 9: srhip_conv2d_fwd whose fp32 output y ALSO leaves as padded split-bf16 planes (y_pp, zeroed once by the caller): the
+ * attention tail's 1x1 conv (sradsgan.py:262-274) hands the next RAB its input in both forms.  *served = 1 when the kernel that
+ * took the launch wrote the planes (the row-group-epilogue kernels of conv_fast.hip), else 0: the caller converts y itself. */
+int srhip_conv2d_fwd_dual(const float* x, const float* packed, const float* bias, const float* residual, const float* rowscale,
+                          const float* chanscale, float* y, void* y_pp, int* served, int n, int h, int w, int cin, int cout, int kh,
+                          int kw, int stride, int pad, int ldx, int ldy, int ldr, float slope, int flags, void* stream) {
+  SRHIP_REQUIRE(y_pp && served && (((uintptr_t)y_pp) & 15) == 0 && ldy == cout, "conv2d_fwd_dual: 16-byte aligned plane buffer, dense fp32 output");
+  g_dst2_req.pp = y_pp;
+  g_dst2_req.served = 0;
+  const int rc = srhip_conv2d_fwd(x, packed, bias, residual, rowscale, chanscale, y, n, h, w, cin, cout, kh, kw, stride, pad, ldx, ldy, ldr,
+                                  slope, flags, stream);
+  *served = g_dst2_req.served;
+  g_dst2_req.pp = nullptr;
+  g_dst2_req.served = 0;
+  return rc;
+}
+
 /* ABI 8: a stride-1 3x3 conv to 64 channels (RAB conv2, sradsgan.py:223) that also leaves the CLAM pooling partials of its
  * output (per channel: sum, NaN-propagating maximum, first arg-max pixel; sradsgan.py:108-121) in `pool`: from the conv's own
  * epilogue when the persistent patch kernel takes the launch, else by srhip_clam_pool_partial on y.  *nseg_out = partial segments

@@ -25,7 +25,16 @@ struct FastGeom {
   // [guard + N (H+1) (W+1) + tail] pixel rows of channels * 4 bytes (per 8 channels: 8 hi | 8 lo halves); Hs / Ws (Hd / Wd) stay the LOGICAL image size
   int src_pp = 0, dst_pp = 0, src_guard = 0, dst_guard = 0;
   unsigned src_plane_bytes = 0, dst_plane_bytes = 0;
+  // a SECOND destination: the fp32 output also as padded planes (the kernels with the row-group epilogue of conv_fast.hip only --
+  // the attention tail's 1x1 conv leaves the next block's input x in both forms); NULL: not wanted
+  void* dst2_pp = nullptr;
+  int dst2_guard = 0;
 };
+struct Dst2Request {                // rides beside ONE srhip_conv2d_fwd call (conv_api.hip: srhip_conv2d_fwd_dual), like PoolRequest
+  void* pp = nullptr;
+  int served = 0;
+};
+extern thread_local Dst2Request g_dst2_req;
 
 __device__ inline float4 bufload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);

@@ -359,6 +359,20 @@ __device__ inline void epi_finish(float4 v, const EpiOps& e, size_t dpix, int n,
   }
   // Conv outputs are streamed out with the non-temporal hint: nothing in this kernel reads them back, and keeping them
   // out of the L2's way is worth 3-4 % on the 64 -> 256 fprop (95.6 MB written) and 0.4 % on the step.
+  if (g.dst2_pp != nullptr) {                       // the same four channels as padded planes: octet n / 8, hi half at + (n & 4) * 2, lo 16 bytes further
+    const unsigned hwd = (unsigned)(g.Hd * g.Wd);
+    const unsigned img = (unsigned)dpix / hwd, rem = (unsigned)dpix - img * hwd;
+    const unsigned oy = rem / (unsigned)g.Wd, ox = rem - oy * (unsigned)g.Wd;
+    const size_t row = (size_t)g.dst2_guard + ((size_t)img * (g.Hd + 1) + oy) * (g.Wd + 1) + ox;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
+    const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
+    const bf16x2_t l01 = {(__bf16)(v.x - __uint_as_float(uh01 << 16)), (__bf16)(v.y - __uint_as_float(uh01 & 0xffff0000u))};
+    const bf16x2_t l23 = {(__bf16)(v.z - __uint_as_float(uh23 << 16)), (__bf16)(v.w - __uint_as_float(uh23 & 0xffff0000u))};
+    unsigned* o2 = static_cast<unsigned*>(g.dst2_pp) + row * g.K + (n >> 3) * 8 + ((n >> 2) & 1) * 2;
+    *reinterpret_cast<uint2*>(o2) = make_uint2(uh01, uh23);
+    *reinterpret_cast<uint2*>(o2 + 4) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+  }
   if (g.flags & 0x400) {                            // srhip_debug_set(3, 0x400): plain stores (A/B)
     *o = v;
     return;
@@ -2444,6 +2458,7 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
   return check_launch("fast_pack_weight");
 }
 
+thread_local Dst2Request g_dst2_req;
 int g_conv_math = 0;     // SRHIP_MATH_*: 0 exact fp32 MFMA; 1 split-bf16 x3 MFMA; 2 one 16-bit product (fp16 activations / bf16 gradients)
 int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
@@ -2708,6 +2723,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
 #define SRHIP_LD(BN_, EPI_)                                                                                        \
   do {                                                                                                             \
     const int nbn = cdiv(g.K, BN_);                                                                                \
+    if (g.dst2_pp) g_dst2_req.served = 1;                                                                          \
     if (g_conv_math == 1) {                                                                                        \
       hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
                          src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm,                      \
@@ -2790,6 +2806,10 @@ int fast_conv2d_fwd(const float* x, const float* packed, const float* bias, cons
   g.ldw = kh * kw * cin; g.ldr = ldr; g.slope = slope; g.flags = flags | g_fast_ablate; g.accumulate = 0; g.dst_identity = 1;
   SRHIP_REQUIRE(bytes_ok((long)n * h * w, ldx, cin, &g.src_bytes), "conv2d_fwd: source tensor >= 2 GiB");
   g.w_bytes = (unsigned)((long)cout * g.ldw * 4);
+  if (g_dst2_req.pp != nullptr && stride == 1 && cout % 8 == 0 && g.OH == g.Hd && g.OW == g.Wd) {   // srhip_conv2d_fwd_dual
+    g.dst2_pp = g_dst2_req.pp;
+    g.dst2_guard = pp_guard(g.Wd);
+  }
   return run_fast(x, packed, bias, residual, rowscale, chanscale, nullptr, y, g, st);
 }
 

@@ -33,6 +33,7 @@ class _State:
     wgrad_group = 1                 # weight gradients of one shape launched together (srhip_conv2d_wgrad_multi); 1 = off
     pending = None                  # shape key -> [(x, dy, gw, gb, stride, pad)] waiting for partners (direct_param_grads mode)
     held = None                     # gradients kept referenced until the backward ends, see _passed_through
+    last_out_pp = None              # _RabBlock.forward -> rab_block(): the output's padded planes (emit_pp)
 
 
 _state = _State()
@@ -322,8 +323,10 @@ def _out_hw(h, w, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None, graddata=False):
-    """graddata: x holds gradients (a second-order pass): 'half' arithmetic then rounds to bf16 instead of fp16."""
+def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=None, chanscale=None, graddata=False, out_pp=None):
+    """graddata: x holds gradients (a second-order pass): 'half' arithmetic then rounds to bf16 instead of fp16.
+    out_pp: a PP buffer that ALSO receives y as padded planes (srhip_conv2d_fwd_dual; a conversion pass when the kernel that took the
+    launch has no second destination)."""
     _require_gpu(x, 'conv2d_fwd')
     x = nhwc(x)
     n, cin, h, wd = x.shape
@@ -350,6 +353,15 @@ def conv2d_fwd_raw(x, w, bias, stride, pad, slope=None, residual=None, rowscale=
     if graddata:
         flags |= EPI_GRADDATA
     lib = _hip.lib()
+    if out_pp is not None:
+        served = ctypes.c_int(0)
+        _hip.check(lib.srhip_conv2d_fwd_dual(_p(x), _p(packed_weight(w, 0)), _p(bias), _p(residual), _p(rowscale),
+                                             _p(chanscale), _p(y), _p(out_pp.buf), ctypes.byref(served),
+                                             n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout, cout,
+                                             float(slope or 0.0), flags, _stream()), 'conv2d_fwd_dual')
+        if not served.value:
+            pp_from_f32(y, out=out_pp)
+        return y
     _hip.check(lib.srhip_conv2d_fwd(_p(x), _p(packed_weight(w, 0)), _p(bias), _p(residual), _p(rowscale),
                                     _p(chanscale), _p(y),
                                     n, h, wd, cin, cout, kh, kw, stride, pad, cin, cout, cout,
@@ -650,8 +662,11 @@ class _PlanePool:
 
 
 plane_pool = _PlanePool()
+if os.environ.get('SRHIP_PERS_GRID'):                          # experiment: blocks of the persistent patch kernel (default: 3 per CU / one per tile)
+    _hip.lib().srhip_debug_set(5, int(os.environ['SRHIP_PERS_GRID']))
 if os.environ.get('SRHIP_FLAT_BLOCKS'):                        # experiment: blocks of the 8-wave weight-gradient kernel (default: one per CU)
     _hip.lib().srhip_debug_set(12, int(os.environ['SRHIP_FLAT_BLOCKS']))
+_X_PP = os.environ.get('SRHIP_X_PP', '1') == '1'                # A/B knob: 0 = a RAB's input never arrives as planes (conversion pass for its weight gradient)
 _DU_PP = os.environ.get('SRHIP_DU_PP', '1') == '1'              # A/B knob: 0 = conv2's gradients read the fp32 du (split in the dgrad kernel, pp_from_f32 pass for the weight gradient)
 _PP_RAB = os.environ.get('SRHIP_PP_RAB', '1') == '1'          # A/B knob: 0 = the RAB keeps t / dt as fp32 tensors (rounds 1-4)
 
@@ -1111,7 +1126,7 @@ def pixel_shuffle_act(x, r, slope=None):
 _TAIL_FUSED = os.environ.get('SRHIP_TAIL_FUSED', '1') == '1'
 
 
-def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
+def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None, out_pp=None):
     """returns (out, tensors to save for _tail_backward).  pool: (buffer, section bytes, nseg) from conv2d_fwd_pool_raw -- the
     pooling partials of u left behind by the conv that produced it (else the tail runs its own pooling pass)."""
     n, c, h, w = u.shape
@@ -1132,7 +1147,7 @@ def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
         _hip.check(lib.srhip_attn_tail_fwd(_p(u), _p(fc1c), _p(fc2c), _p(w7c), _p(avg), _p(mx), _p(arg), _p(s),
                                            _p(pooled), _p(argc), _p(m), _p(ws), ws.numel() * 4, n, h, w, c,
                                            fc1_w.shape[0], _stream()), 'attn_tail_fwd')
-    out = conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s)
+    out = conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s, out_pp=out_pp)      # out_pp: the block output also as padded planes
     return out, (avg, mx, arg, s, pooled, argc, m)
 
 
@@ -1236,22 +1251,26 @@ class _RabBlock(Function):
     gradient-accumulation adds, 3 saved activations (x, t, u) instead of ~12."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
+    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp=None, emit_pp=False):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
-        ctx.t_pp = None
+        ctx.t_pp = ctx.x_pp = None
+        _state.last_out_pp = None
         if rab_planes_ok(x, w1, w2):
             # round 5: t stays in padded split-bf16 planes between the block's own kernels (conv1's epilogue writes them, conv2 reads
-            # them without its in-place split, the backward's activation mask and weight gradient read them again)
+            # them without its in-place split, the backward's activation mask and weight gradient read them again).  x_pp: the block
+            # input ALSO as planes, left by the previous block's tail (emit_pp): conv1 and its weight gradient read them
             n, _, h, wd = x.shape
             t_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
-            conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=t_pp)
+            conv2d_fwd_pp_raw(x_pp if x_pp is not None else x, w1, b1, 0.2, out_pp=t_pp)
             if pool_epilogue_ok(x, w2):
                 u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2, pool=True)
             else:
                 u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2), None
-            out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
-            ctx.t_pp = t_pp
+            out_pp = plane_pool.get(n, x.shape[1], h, wd, x.device) if emit_pp else None
+            out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc, pool, out_pp=out_pp)
+            _state.last_out_pp = out_pp
+            ctx.t_pp, ctx.x_pp = t_pp, x_pp
             ctx.save_for_backward(x, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved)
             ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
             return out
@@ -1280,7 +1299,7 @@ class _RabBlock(Function):
         dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g) if ctx.needs_input_grad[0] else None   # + skip gradient
         if not skip:
             dw1, db1 = wgrad_for_params(w1, b1, x, dt, 1, 1, ctx.has_b[0])
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None
 
     @staticmethod
     def _backward_planes(ctx, g):
@@ -1289,6 +1308,7 @@ class _RabBlock(Function):
         converted on the weight-gradient stream)."""
         x, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
         t_pp, ctx.t_pp = ctx.t_pp, None
+        x_pp, ctx.x_pp = ctx.x_pp, None
         g = nhwc(g)
         skip = _skip_param_grads()
         n, _, h, wd = x.shape
@@ -1308,7 +1328,8 @@ class _RabBlock(Function):
                 dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du, 1, 1, ctx.has_b[1])
         dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g) if ctx.needs_input_grad[0] else None   # + skip gradient
         if not skip:
-            dt_done = wgrad_pp_for_params(w1, b1, x, dt_pp, ctx.has_b[0], release=(dt_pp,))
+            dt_done = wgrad_pp_for_params(w1, b1, x_pp if x_pp is not None else x, dt_pp, ctx.has_b[0],
+                                          release=(dt_pp,) if x_pp is None else (dt_pp, x_pp))
             if not dt_done:
                 dw1, db1 = wgrad_for_params(w1, b1, x, pp_to_f32(dt_pp), 1, 1, ctx.has_b[0])
         if not t_done:
@@ -1317,10 +1338,12 @@ class _RabBlock(Function):
                 plane_pool.put(du_pp, (main,))
         if not dt_done:
             plane_pool.put(dt_pp, (main,))
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc
+            if x_pp is not None:
+                plane_pool.put(x_pp, (main,))
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None
 
 
-def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
+def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
     if _tail_eval_ok(x):                                 # inference: three conv-sized launches + the pooling partials per block
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
@@ -1340,7 +1363,17 @@ def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc):
         else:
             u, pool = conv2d_fwd_raw(t, w2, b2, 1, 1), None
         return _tail_forward_eval(u, x, fc1_w, fc2_w, w7, wc, bc, pool)
-    return _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc)
+    # emit_pp (the caller knows that another RAB consumes the output): the tail's 1x1 conv leaves the output also as padded planes; they
+    # travel as an attribute of the output tensor (with its version counter: an in-place change of the tensor voids them)
+    x_pp = None
+    tag = getattr(x, '_srhip_pp', None) if _X_PP else None
+    if tag is not None and tag[1] == x._version and tag[0].shape == tuple(x.shape):
+        x_pp = tag[0]
+    out = _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp, bool(emit_pp and _X_PP))
+    pp, _state.last_out_pp = getattr(_state, 'last_out_pp', None), None
+    if pp is not None:
+        out._srhip_pp = (pp, out._version)
+    return out
 
 
 def attention_tail_supported(u, fc1_w, w7, wc):

@@ -132,3 +132,51 @@ def test_eight_wave_patch_kernel_is_bit_identical_to_the_four_wave_kernels(case)
                 lib.srhip_debug_set(15, 0)
         for a, b in zip(res[0], res[1]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', [(2, 23, 37), (32, 54, 54), (3, 9, 20)])
+def test_tail_conv_leaves_its_output_also_as_padded_planes(case):
+    """srhip_conv2d_fwd_dual: the attention tail's 1x1 conv (bias + residual + row / channel scales, the row-group epilogue of
+    conv_fast.hip) writes y as fp32 AND as padded planes = exactly pp_from_f32(y); a conv whose kernel has no second destination
+    (3x3 patch kernel) falls back to the conversion pass behind the same call."""
+    from sradsgan_amd import ops
+    n, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + 31)
+    u, skip = _cl(torch.randn(n, 64, h, w, generator=g)), _cl(torch.randn(n, 64, h, w, generator=g))
+    wc = torch.nn.Parameter((torch.randn(64, 64, 1, 1, generator=g) * 0.1).to(DEV))
+    bc = torch.randn(64, generator=g).to(DEV)
+    m, s = torch.rand(n * h * w, generator=g).to(DEV), torch.rand(n, 64, generator=g).to(DEV)
+    with ops.conv_math('bf16x3'):
+        y0 = ops.conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s)
+        pp = ops.pp_empty(n, 64, h, w, DEV)
+        y1 = ops.conv2d_fwd_raw(u, wc, bc, 1, 0, None, skip, m, s, out_pp=pp)
+        assert torch.equal(y0, y1) and torch.equal(pp.buf, ops.pp_from_f32(y0).buf)
+        w3 = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV))
+        pp3 = ops.pp_empty(n, 64, h, w, DEV)
+        y3 = ops.conv2d_fwd_raw(u, w3, bc, 1, 1, out_pp=pp3)
+        assert torch.equal(pp3.buf, ops.pp_from_f32(y3).buf)
+
+
+def test_rab_chain_with_handed_over_input_planes_is_bit_identical():
+    """Three RABs in a row at the bench's tile size: with the block outputs handed over as padded planes (the tail conv's second
+    destination, conv1 and its weight gradient reading them) the output, the input gradient and every parameter gradient equal the
+    chain in which every block converts for itself (SRHIP_X_PP=0 behaviour)."""
+    from sradsgan_amd import ops, model as M
+    torch.manual_seed(5)
+    blocks = torch.nn.ModuleList([M.RAB(64, 64) for _ in range(3)]).to(DEV)
+    x0 = _cl(torch.randn(8, 64, 54, 54, device=DEV))
+    res = []
+    with ops.conv_math('bf16x3'):
+        for hand_over in (False, True):
+            for p in blocks.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            out = x
+            for i, b in enumerate(blocks):
+                b._next_is_rab = hand_over and i < 2
+                out = b(out)
+            out.square().mean().backward()
+            torch.cuda.synchronize()
+            res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blocks.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -39,8 +39,8 @@ for mode in ('fp32', 'bf16x3', 'half'):
                 continue
             c = pmc[k]
             weight = (len(c.get('FETCH_SIZE', [])) / main_calls) if (main_calls and aux(k)) else 1.0
-            if not aux(k) and main_calls and len(c.get('FETCH_SIZE', [])) < main_calls // 2:
-                weight = 0.0                                         # a kernel timed only for comparison (e.g. the row-tap pair beside the flat kernel)
+            if not aux(k) and main_calls and len(c.get('FETCH_SIZE', [])) < main_calls:
+                weight = 0.0                                         # a kernel timed only for comparison beside the main one
             avg = lambda name: (sum(c[name]) / len(c[name])) if c.get(name) else 0.0
             fetch, write = avg('FETCH_SIZE') * 1024 * 2, avg('WRITE_SIZE') * 1024
             calls, ns = stats.get(k, (0, 0.0))

@@ -29,5 +29,10 @@ for B in (32, 16):
         ('conv2 dgrad 64->256 actmask', lambda: ops.conv2d_dgrad_raw(du, w2, tuple(tt.shape), 1, 1, None, tt, 0.2), lambda: ops.conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=out_pp)),
         ('conv1 dgrad 256->64 residual', lambda: ops.conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g), lambda: ops.conv2d_dgrad_pp_raw(dt_pp, w1, residual=g)),
     ]
+    x_pp = ops.pp_from_f32(x); du_pp = ops.pp_from_f32(du)
+    rows += [
+        ('conv1 fprop, x ALSO planes', lambda: ops.conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=out_pp), lambda: ops.conv2d_fwd_pp_raw(x_pp, w1, b1, 0.2, out_pp=out_pp)),
+        ('conv2 dgrad, du ALSO planes', lambda: ops.conv2d_dgrad_pp_raw(du, w2, actmask=t_pp, slope=0.2, out_pp=out_pp), lambda: ops.conv2d_dgrad_pp_raw(du_pp, w2, actmask=t_pp, slope=0.2, out_pp=out_pp)),
+    ]
     for name, f32, pp in rows:
         print('B=%2d %-32s fp32 tensors %6.1f us   planes %6.1f us' % (B, name, t(f32), t(pp)))
