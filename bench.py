@@ -308,8 +308,26 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
             wgrad_extra['conversion_pass_ms'] = round(_time_launches(lambda: ops.pp_from_f32(x, out=ppx_scratch), 200), 4)
             wgrad_extra['rowtap_pair_launch_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_multi_raw(items), 200), 4)
         single_wgrad = lambda: ops.conv2d_wgrad_pp_raw(pitems[:1])
+    fprop_fn = lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)
+    fprop_extra = {}
+    if math == 'bf16x3' and ops.rab_planes_ok(x, w, torch.empty(64, 256, 3, 3, device='meta')):
+        # Round 5: the step runs RAB conv1 on padded split-bf16 planes -- x arrives as planes (from the previous block's tail conv, or
+        # from one pp_from_f32 pass for the first block of a ResGroup: counted with the weight gradient, which shares it), t = LeakyReLU(conv1 x)
+        # leaves as planes.  Timed: exactly that launch (same kernel template, same FLOPs and algorithmic bytes as the fp32-tensor form:
+        # a plane row is the 4 bytes per channel the fp32 row has), on three operand sets in rotation (360 MB: the 256 MB Infinity Cache
+        # never holds a launch's operands); the fp32-tensor form of rounds 1-4 is timed beside it (`fp32_tensors_launch_ms`).
+        fsets = [(ops.pp_from_f32(x if k == 0 else torch.randn_like(x)), ops.pp_empty(batch, 256, LR_SIDE, LR_SIDE, device)) for k in range(3)]
+        frot = [0]
+
+        def fprop_pp():
+            frot[0] = (frot[0] + 1) % 3
+            ops.conv2d_fwd_pp_raw(fsets[frot[0]][0], w, b, 0.2, out_pp=fsets[frot[0]][1])
+        fprop_fn = fprop_pp
+        kf = 'conv_patch_pers_kernel<128,bias+lrelu,x planes -> t planes> (persistent tile walk), operands cold (three sets in rotation)'
+        if with_single:
+            fprop_extra['fp32_tensors_launch_ms'] = round(_time_launches(lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2), 300), 4)
     for key, kernel, fn in (
-            ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2)),
+            ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', fprop_fn),
             ('wgrad', kw_label + ': 3x3 64->256 @54x54 wgrad (RAB conv1)', wgrad_fn)):
         calls = wgrad_calls if key == 'wgrad' else 1        # launches per call of fn (the weight-gradient mix issues three)
         flops = 2.0 * batch * LR_SIDE * LR_SIDE * 256 * 64 * 9 * (group if key == 'wgrad' else 1)
@@ -368,6 +386,10 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         rec['launches_timed'] = n * calls
         rec['achieved'] = round(flops / (sus * 1e-3) / 1e12, 2)
         rec['frac'] = round(rec['achieved'] / peak, 4)
+        if key == 'fprop':
+            for k2, v2 in fprop_extra.items():
+                rec[k2] = v2
+                rec['fp32_tensors_frac'] = round(flops / (v2 * 1e-3) / 1e12 / peak, 4)
         if key == 'wgrad':
             for k2, v2 in wgrad_extra.items():
                 rec[k2] = v2

@@ -477,9 +477,13 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
     const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
     const bf16x2_t l01 = {(__bf16)(d.x - __uint_as_float(uh01 << 16)), (__bf16)(d.y - __uint_as_float(uh01 & 0xffff0000u))};
     const bf16x2_t l23 = {(__bf16)(d.z - __uint_as_float(uh23 << 16)), (__bf16)(d.w - __uint_as_float(uh23 & 0xffff0000u))};
-    unsigned* o = du_pp + row * TC + (cq >> 1) * 8 + (cq & 1) * 2;       // dwords: octet * 8, hi half at +0 / +2, lo half at +4 / +6
-    *reinterpret_cast<uint2*>(o) = make_uint2(uh01, uh23);
-    *reinterpret_cast<uint2*>(o + 4) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    // the two lanes of an octet trade halves: the even lane stores the octet's 8 hi halves, the odd lane its 8 lo halves, 16 bytes each
+    // (whole rows per store instruction; see epi_finish in conv_fast.hip)
+    const bool odd = (cq & 1) != 0;
+    const unsigned ul01 = __builtin_bit_cast(unsigned, l01), ul23 = __builtin_bit_cast(unsigned, l23);
+    const unsigned r0 = pair_swap(odd ? uh01 : ul01), r1 = pair_swap(odd ? uh23 : ul23);
+    unsigned* o = du_pp + row * TC + (cq >> 1) * 8 + (odd ? 4 : 0);
+    *reinterpret_cast<uint4*>(o) = odd ? make_uint4(r0, r1, ul01, ul23) : make_uint4(uh01, uh23, r0, r1);
   }
 }
 

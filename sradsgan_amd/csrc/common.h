@@ -45,6 +45,11 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// value of the neighbouring lane (lane ^ 1) through the DPP network: quad_perm [1, 0, 3, 2]; both lanes of a pair must be active
+__device__ __forceinline__ unsigned pair_swap(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
 // max-pool comparisons propagate NaN like ATen's (adaptive_max_pool2d / max(dim)): a NaN beats every number, the first
 // NaN wins among NaNs -- a NaN activation must surface in the loss, not be masked by an attention gate (cbam.hip: the
 // discriminator's pair; attn_tail.hip: the generator's 48 CLAM / SLAM pools)

@@ -369,9 +369,14 @@ __device__ inline void epi_finish(float4 v, const EpiOps& e, size_t dpix, int n,
     const unsigned uh01 = __builtin_bit_cast(unsigned, h01), uh23 = __builtin_bit_cast(unsigned, h23);
     const bf16x2_t l01 = {(__bf16)(v.x - __uint_as_float(uh01 << 16)), (__bf16)(v.y - __uint_as_float(uh01 & 0xffff0000u))};
     const bf16x2_t l23 = {(__bf16)(v.z - __uint_as_float(uh23 << 16)), (__bf16)(v.w - __uint_as_float(uh23 & 0xffff0000u))};
-    unsigned* o2 = static_cast<unsigned*>(g.dst2_pp) + row * g.K + (n >> 3) * 8 + ((n >> 2) & 1) * 2;
-    *reinterpret_cast<uint2*>(o2) = make_uint2(uh01, uh23);
-    *reinterpret_cast<uint2*>(o2 + 4) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    // The two lanes of an octet (adjacent lanes, adjacent quads: the row-group loop's mapping) trade halves so that each stores ONE whole
+    // 16-byte piece -- the even lane the octet's 8 hi halves, the odd lane its 8 lo halves: a store instruction then writes whole rows
+    // (two 8-byte stores per lane wrote 16 bytes of every 32 per instruction and the memory side counted them as partial lines).
+    const bool odd = ((n >> 2) & 1) != 0;
+    const unsigned ul01 = __builtin_bit_cast(unsigned, l01), ul23 = __builtin_bit_cast(unsigned, l23);
+    const unsigned r0 = pair_swap(odd ? uh01 : ul01), r1 = pair_swap(odd ? uh23 : ul23);   // even lane receives the odd lane's hi, odd lane the even lane's lo
+    unsigned* o2 = static_cast<unsigned*>(g.dst2_pp) + row * g.K + (n >> 3) * 8 + (odd ? 4 : 0);
+    *reinterpret_cast<uint4*>(o2) = odd ? make_uint4(r0, r1, ul01, ul23) : make_uint4(uh01, uh23, r0, r1);
   }
   if (g.flags & 0x400) {                            // srhip_debug_set(3, 0x400): plain stores (A/B)
     *o = v;

@@ -534,51 +534,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     zero_acc();
   };
 
-  // ---- epilogue onto padded planes: the same four 16-row passes, a lane serves 8 channels (two float4 of the staged row) of
-  // 64 / OPR rows per pass and stores them as 8 hi + 8 lo halves: NS stores per tile like the fp32 form
+  // ---- epilogue onto padded planes: the same four 16-row passes.  A plane row holds the bytes of the fp32 row (per 8 channels: 8 hi | 8 lo
+  // halves = 32 bytes), so the STORES are those of the fp32 form -- lane = one 16-byte piece, 64 / QPRW rows per instruction, every
+  // instruction writes whole 256-byte (BN = 128) / 128-byte (BN = 64) runs.  Between staging and the stores each lane converts 8
+  // channels of 64 / OPR rows IN PLACE inside its wave's staging buffer (two float4 in, bias / LeakyReLU / mask, split, 8 hi + 8 lo out).
+  // (First form, until round 5's last day: the converting lane stored its own hi and lo pieces, i.e. every store instruction wrote
+  // 16 bytes of each 32: the memory side counted 131.9 MB for 95.6 MB of output and the launch ran 79.5 us against 74.5 for an fp32
+  // destination, profiles/r05_roofline_pmc_summary.txt.)
   auto epilogue_pp = [&](const TileAt& t) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr int OPR = WTN / 8;                        // 8-channel groups per staged row
-    constexpr int NRP = 16 * OPR / 64;                  // rows per lane per pass
-    static_assert(2 * NRP == NRD, "hi + lo stores = the fp32 form's store count");
+    constexpr int NRP = 16 * OPR / 64;                  // (row, group) items per lane per pass
     float* wl = reinterpret_cast<float*>(wave < 3 ? lds + PATCH_B + wave * STG_B : lds + RING0 + 2 * BSTAGE_B);
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int l31e = ln & 31, khe = ln >> 5;
+    // conversion mapping: lane = group oq of rows i * (64 / OPR) + rsub
     const int oq = ln & (OPR - 1), rsub = ln / OPR;
     const int n = t.n0 + wn * WTN + oq * 8;
     const bool nok = n < g.K;
     const int ns = nok ? n : 0;
-    const unsigned tile_base = (unsigned)((g.dst_guard + (t.img * (g.Hd + 1) + t.oh0) * (g.Wd + 1) + t.ow0) * g.K + n) * 4u;   // 8 channels = 32 bytes: [8 hi | 8 lo]
+    const unsigned row0 = (unsigned)((g.dst_guard + (t.img * (g.Hd + 1) + t.oh0) * (g.Wd + 1) + t.ow0) * g.K) * 4u;   // byte offset of the tile's first pixel row
+    const unsigned tile_base = row0 + (unsigned)n * 4u;                                                                 // 8 channels = 32 bytes: [8 hi | 8 lo]
+    // store mapping: lane = 16-byte piece cq of rows i * (64 / QPRW) + rsub2 (the fp32 form's)
+    const int cq = ln & (QPRW - 1), rsub2 = ln / QPRW;
+    const int n2 = t.n0 + wn * WTN + cq * 4;
+    const bool nok2 = n2 < g.K;
+    const unsigned tile_base2 = row0 + (unsigned)n2 * 4u;
     const bool interior = t.oh0 + pg.PH <= g.OH && t.ow0 + pg.PW <= g.OW;
     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
     if (flags & SRHIP_EPI_BIAS) {
       b0 = *reinterpret_cast<const float4*>(bias_s + ns);
       b1 = *reinterpret_cast<const float4*>(bias_s + ns + 4);
     }
-    auto pass_offsets = [&](int p, unsigned (&doff)[NRP], bool (&okv)[NRP]) {
+    auto row_ok = [&](int rr, unsigned& rel) {
+      rel = rel_tab[rr];
+      bool ok = rel < F_OOB;
+      if (!interior) {
+        const int pt = pix_tab[rr];
+        ok = ok && t.oh0 + (pt >> 16) < g.OH && t.ow0 + (pt & 0xffff) < g.OW;
+      }
+      return ok;
+    };
+    auto mask_offsets = [&](int p, unsigned (&doff)[NRP]) {           // where the conversion mapping finds its mask pieces
 #pragma unroll
       for (int i = 0; i < NRP; ++i) {
-        const int rr = wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + i * (64 / OPR) + rsub;
-        const unsigned rel = rel_tab[rr];
-        bool ok = nok && rel < F_OOB;
-        if (!interior) {
-          const int pt = pix_tab[rr];
-          ok = ok && t.oh0 + (pt >> 16) < g.OH && t.ow0 + (pt & 0xffff) < g.OW;
-        }
-        okv[i] = ok;
+        unsigned rel;
+        const bool ok = row_ok(wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + i * (64 / OPR) + rsub, rel) && nok;
         doff[i] = ok ? tile_base + rel : 0u;
       }
     };
     u32x4 am[2][NRP];                                   // mask = the hi halves of the producer's activation output (same geometry)
-    unsigned doffs[2][NRP];
-    bool oks[2][NRP];
-    pass_offsets(0, doffs[0], oks[0]);
+    unsigned moff[NRP];
     if (flags & SRHIP_EPI_ACTMASK) {
+      mask_offsets(0, moff);
 #pragma unroll
-      for (int i = 0; i < NRP; ++i) am[0][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + doffs[0][i]);
+      for (int i = 0; i < NRP; ++i) am[0][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + moff[i]);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -587,19 +600,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       for (int u = 0; u < TN; ++u)
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
-      if (p < 3) {
-        pass_offsets(p + 1, doffs[nx], oks[nx]);
-        if (flags & SRHIP_EPI_ACTMASK) {
+      if (p < 3 && (flags & SRHIP_EPI_ACTMASK)) {       // (before this pass's stores are issued: see the fp32 form)
+        mask_offsets(p + 1, moff);
 #pragma unroll
-          for (int i = 0; i < NRP; ++i) am[nx][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + doffs[nx][i]);
-        }
+        for (int i = 0; i < NRP; ++i) am[nx][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + moff[i]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < NRP; ++i) {
-        const int row = i * (64 / OPR) + rsub;
-        const float4 v0 = *reinterpret_cast<const float4*>(wl + row * WTN + oq * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(wl + row * WTN + oq * 8 + 4);
+      for (int i = 0; i < NRP; ++i) {                   // in-place conversion of this lane's 32-byte items
+        float* item = wl + (i * (64 / OPR) + rsub) * WTN + oq * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(item);
+        const float4 v1 = *reinterpret_cast<const float4*>(item + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (flags & SRHIP_EPI_BIAS) {
           v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -619,10 +630,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         bf16x8_t hi, lo;
         split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
-        const unsigned doff = doffs[cur][i];
-        const bool ok = oks[cur][i];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rs_d, ok ? doff : F_OOB + 32u * (unsigned)(p * NRP + i), 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rs_d, ok ? doff + 16u : F_OOB + 32u * (unsigned)(p * NRP + i) + 16u, 0, 2);
+        *reinterpret_cast<u32x4*>(item) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(item + 4) = __builtin_bit_cast(u32x4, lo);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave, one staging buffer: the wave's own LDS writes are all it waits for)
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        const int row = i * (64 / QPRW) + rsub2;
+        unsigned rel;
+        const bool ok = row_ok(wm * WTM + (p >> 1) * 32 + (p & 1) * 16 + row, rel) && nok2;
+        const u32x4 piece = *reinterpret_cast<const u32x4*>(wl + row * WTN + cq * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(piece, rs_d, ok ? tile_base2 + rel : F_OOB + 16u * (unsigned)(p * NRD + i), 0, 2);
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

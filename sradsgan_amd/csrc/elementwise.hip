@@ -88,32 +88,35 @@ __global__ void pixel_shuffle_fwd_kernel(const float* __restrict__ in, float* __
   reinterpret_cast<float4*>(out)[idx] = v;
 }
 
+// Gather form: one thread per 4 consecutive INPUT channels of one input pixel -- a 16-byte store per lane, whole rows per store
+// instruction; the four sources are scalar loads that consecutive lanes take from consecutive channels (r = 2: the same output pixel).
+// (The scatter form of rounds 1-4 -- one thread per output quad, four 4-byte stores 16 bytes apart -- made the memory side write
+// 478 MB for a 239 MB tensor: profiles/r05_step_traffic.txt.)
 __global__ void pixel_shuffle_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outv,
                                          float* __restrict__ din, int n, int h, int w, int c, int r, float slope,
                                          int act) {
-  long total = (long)n * h * r * w * r * (c / 4);
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int rr = r * r, cin4 = c * rr / 4;
+  const long total = (long)n * h * w * cin4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  int c4 = (int)(idx % (c / 4));
-  long pix = idx / (c / 4);
-  int ow = (int)(pix % (w * r));
-  long t = pix / (w * r);
-  int oh = (int)(t % (h * r));
-  int b = (int)(t / (h * r));
-  int hh = oh / r, i = oh - hh * r, ww = ow / r, j = ow - ww * r;
-  float4 g = reinterpret_cast<const float4*>(dout)[idx];
-  if (act) {
-    float4 v = reinterpret_cast<const float4*>(outv)[idx];
-    g.x = v.x > 0.f ? g.x : g.x * slope;
-    g.y = v.y > 0.f ? g.y : g.y * slope;
-    g.z = v.z > 0.f ? g.z : g.z * slope;
-    g.w = v.w > 0.f ? g.w : g.w * slope;
+  const int q = (int)(idx % cin4);
+  long pix = idx / cin4;
+  const int ww = (int)(pix % w);
+  pix /= w;
+  const int hh = (int)(pix % h);
+  const int b = (int)(pix / h);
+  float g[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int cc = q * 4 + e;
+    const int co = cc / rr, ij = cc - co * rr;
+    const int i = ij / r, j = ij - i * r;
+    const size_t o = (((size_t)b * (h * r) + (hh * r + i)) * (size_t)(w * r) + (ww * r + j)) * (size_t)c + co;
+    float v = dout[o];
+    if (act) v = outv[o] > 0.f ? v : v * slope;
+    g[e] = v;
   }
-  float* d = din + ((size_t)(b * h + hh) * w + ww) * ((size_t)c * r * r) + (size_t)(c4 * 4) * r * r + i * r + j;
-  d[0] = g.x;
-  d[r * r] = g.y;
-  d[2 * r * r] = g.z;
-  d[3 * r * r] = g.w;
+  reinterpret_cast<float4*>(din)[idx] = make_float4(g[0], g[1], g[2], g[3]);
 }
 
 // nn.MaxPool2d(2, 2) on NHWC (vgg19.features[4], [9]); one thread per 4 channels of one output pixel.
@@ -342,7 +345,8 @@ int srhip_pixel_shuffle_bwd(const float* dout, const float* out, float* din, int
   SRHIP_REQUIRE(dout && din && (out || !apply_act) && n >= 0 && h > 0 && w > 0 && cout > 0 && r > 0,
                 "pixel_shuffle_bwd: bad argument");
   SRHIP_REQUIRE(cout % 4 == 0, "pixel_shuffle_bwd: output channels must be a multiple of 4");
-  long total = (long)n * h * r * w * r * (cout / 4);
+  SRHIP_REQUIRE((cout * r * r) % 4 == 0, "pixel_shuffle_bwd: input channels must be a multiple of 4");
+  long total = (long)n * h * w * (cout * r * r / 4);
   if (total == 0) return SRHIP_OK;
   hipLaunchKernelGGL(pixel_shuffle_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), dout, out, din,
                      n, h, w, cout, r, slope, apply_act);

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/roof2
 cd /tmp && export TMPDIR=/tmp
-for M in fp32 bf16x3 half; do
+for M in ${MODES:-fp32 bf16x3 half}; do
   O=$R/gpurun_out/roof2/$M
   mkdir -p $O
   rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --roofline-only --conv-math $M > $O/kt.log 2>&1
