@@ -14,22 +14,82 @@ struct PackEntry {
   float* packed;
   int cout, cin, kh, kw, mode, fast;
 };
-__global__ void pack_batched_kernel(const PackEntry* __restrict__ tab) {
+// Fast entries, round 5: a block walks tiles of RO weight rows (co) x CI source channels (ci) x all taps -- 8 x 64 for the forward
+// operand, 32 x 16 for the data-gradient operand (whose 8-channel groups run along co).  The tile is read as it lies (contiguous pieces
+// of w[co][ci0 ..][.], coalesced) into LDS and written in two passes of 16-byte stores, each in the order of ITS sections:
+//   A: a thread = one 8-channel group of one (destination channel, tap): 32 bytes of the fp32, the split-bf16 (8 hi | 8 lo) and the
+//      fp16 (8 | zeros) section; consecutive threads walk the channels of a row: runs of 128 - 256 bytes;
+//   B: a thread = one 64-byte row (16-channel chunk, tap, destination channel) of the tiled section, its four quads swizzled;
+//      consecutive threads walk the destination channels: runs of 512 - 1024 bytes.
+// (conv_internal.h: fast_pack_store describes the layout element by element; this kernel writes the same bytes.  The element-wise
+// form read w with a 36-byte stride and stored 2-byte scalars: 623 MB read + 542 MB written per step for 63 MB of weights, 407 us on
+// the step's serial tail, profiles/r05_step_traffic.txt.)
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ tab) {
   const PackEntry e = tab[blockIdx.y];
   const int khkw = e.kh * e.kw;
   if (e.fast) {
+    constexpr int LDS_F = 32 * (16 * 9 + 1);                     // >= 8 * (64 * 9 + 1)
+    __shared__ float tile[LDS_F];
     const long total = (long)e.cout * e.cin * khkw;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-      if (e.mode == 0) {
-        const int co = (int)(idx / (khkw * e.cin));
-        const int rem = (int)(idx - (long)co * khkw * e.cin);
-        const int tap = rem / e.cin, ci = rem - tap * e.cin;
-        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap], e.cout, e.cin, khkw);
-      } else {
-        const int ci = (int)(idx / (khkw * e.cout));
-        const int rem = (int)(idx - (long)ci * khkw * e.cout);
-        const int tap = rem / e.cout, co = rem - tap * e.cout;
-        fast_pack_store(e.packed, total, idx, e.w[((size_t)co * e.cin + ci) * khkw + tap], e.cin, e.cout, khkw);
+    const int RO = e.mode == 0 ? 8 : 32;
+    const int CI = e.mode == 0 ? (khkw <= 9 ? 64 : 16) : (khkw <= 9 ? 16 : 4);
+    const int ld = CI * khkw + 1;                                // (+1: rows on different banks)
+    const int nci = (e.cin + CI - 1) / CI, nco = (e.cout + RO - 1) / RO;
+    const int ndst = e.mode == 0 ? e.cout : e.cin, csrc = e.mode == 0 ? e.cin : e.cout;
+    const long ndst16 = ((long)ndst + 15) / 16 * 16;
+    float* s0 = e.packed;
+    char* s1 = reinterpret_cast<char*>(e.packed + total);
+    char* s2 = reinterpret_cast<char*>(e.packed + 2 * total);
+    char* s3 = reinterpret_cast<char*>(e.packed + 3 * total);
+    for (int t = blockIdx.x; t < nci * nco; t += gridDim.x) {
+      const int co0 = (t / nci) * RO, ci0 = (t % nci) * CI;
+      const int cw = min(CI, e.cin - ci0), rw = min(RO, e.cout - co0);   // channels / rows of this tile
+      const int rowlen = cw * khkw;
+      __syncthreads();
+      for (int i = threadIdx.x; i < rw * rowlen; i += 256) {
+        const int r = i / rowlen, k = i - r * rowlen;
+        tile[r * ld + k] = e.w[((size_t)(co0 + r) * e.cin + ci0) * khkw + k];
+      }
+      __syncthreads();
+      // element (destination channel n, tap, source channel c) of the tile: mode 0: n = co0 + a, c = ci0 + b; mode 1: n = ci0 + b, c = co0 + a
+      auto at = [&](int a, int b, int tap) { return tile[a * ld + b * khkw + tap]; };
+      const int nn = e.mode == 0 ? rw : cw, nc = e.mode == 0 ? cw : rw;  // destination channels / source channels of the tile
+      const int n0 = e.mode == 0 ? co0 : ci0, c00 = e.mode == 0 ? ci0 : co0;
+      // ---- pass A: row-major sections, source channels fastest
+      for (int it = threadIdx.x; it < nn * khkw * (nc / 8); it += 256) {
+        const int g8 = it % (nc / 8), rt = it / (nc / 8);
+        const int tap = rt % khkw, dn = rt / khkw;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = e.mode == 0 ? at(dn, g8 * 8 + j, tap) : at(g8 * 8 + j, dn, tap);
+        const long idx = ((long)(n0 + dn) * khkw + tap) * csrc + c00 + g8 * 8;   // first element of the group (idx % 8 == 0)
+        reinterpret_cast<float4*>(s0 + idx)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(s0 + idx)[1] = make_float4(v[4], v[5], v[6], v[7]);
+        bf16x8_t hi, lo;
+        split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+        *reinterpret_cast<u32x4*>(s1 + idx * 4) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(s1 + idx * 4 + 16) = __builtin_bit_cast(u32x4, lo);
+        const f16x8_t f16 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(s2 + idx * 4) = __builtin_bit_cast(u32x4, f16);
+        *reinterpret_cast<u32x4*>(s2 + idx * 4 + 16) = z;
+      }
+      // ---- pass B: tiled section, destination channels fastest (c00 % 16 == 0: the tile starts on a chunk boundary)
+      for (int it = threadIdx.x; it < nn * khkw * (nc / 16); it += 256) {
+        const int dn = it % nn, rt = it / nn;
+        const int tap = rt % khkw, g16 = rt / khkw;
+        const int n = n0 + dn, swz = (n >> 2) & 3;
+        char* row = s3 + (((long)((c00 >> 4) + g16) * khkw + tap) * ndst16 + n) * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = e.mode == 0 ? at(dn, g16 * 16 + h * 8 + j, tap) : at(g16 * 16 + h * 8 + j, dn, tap);
+          bf16x8_t hi, lo;
+          split_bf16x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+          *reinterpret_cast<u32x4*>(row + (((2 * h) ^ swz) << 4)) = __builtin_bit_cast(u32x4, hi);
+          *reinterpret_cast<u32x4*>(row + (((2 * h + 1) ^ swz) << 4)) = __builtin_bit_cast(u32x4, lo);
+        }
       }
     }
   } else {

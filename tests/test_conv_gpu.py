@@ -627,3 +627,27 @@ def test_stream_fork_orders_the_side_stream_behind_the_current_one():
             assert float(out.min()) == float(out.max()) == 6.0 * (it + 1), (it, float(out.min()), float(out.max()))
     torch.cuda.synchronize()
     assert float(out.min()) == float(out.max()) == 1200.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cout,cin,k', [(256, 64, 3), (64, 256, 3), (3, 64, 3), (64, 3, 3), (64, 64, 1), (512, 512, 3), (128, 64, 5), (64, 48, 3), (8, 64, 1), (1, 512, 3)])
+def test_batched_repack_writes_the_bytes_of_the_single_pack(cout, cin, k):
+    """srhip_pack_weights_batched (one launch after every optimiser step: tiles through LDS, 16-byte stores) against srhip_pack_weight
+    (element-wise) for both operand roles: every section of the packed image byte for byte."""
+    import struct
+    from sradsgan_amd import _hip
+    lib = _hip.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(cout * 131 + cin * 7 + k)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.3).to(dev)
+    for mode in (0, 1):
+        n = lib.srhip_packed_elems(cout, cin, k, k, mode)
+        one = torch.zeros(n, device=dev)
+        many = torch.zeros(n, device=dev)
+        _hip.check(lib.srhip_pack_weight(w.data_ptr(), one.data_ptr(), cout, cin, k, k, mode, None))
+        fast = lib.srhip_packed_is_fast(cout, cin, k, k, mode)
+        blob = struct.pack('<QQiiiiii', w.data_ptr(), many.data_ptr(), cout, cin, k, k, mode, fast)
+        tab = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        _hip.check(lib.srhip_pack_weights_batched(tab.data_ptr(), 1, None))
+        torch.cuda.synchronize()
+        assert torch.equal(one.view(torch.int32), many.view(torch.int32)), (mode, fast)
