@@ -193,6 +193,17 @@ int srhip_conv2d_fwd_pp(const void* x, int x_pp, const float* packed, const floa
                         int* nseg_out, int n, int h, int w, int cin, int cout, float slope, int flags, void* stream);
 int srhip_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* dx, int dx_pp, const float* residual, const void* actmask,
                           float slope, int n, int h, int w, int cin, int cout, void* stream);
+/* The data gradient of a 3x3 stride-1 (any fast-path) conv with up to THREE residuals of dx's geometry, contiguous rows (ld = cin):
+ * dx = conv_transpose(dy, w) + residual + residual2 + residual3, added in this order (residual2 or residual3 may be NULL).  Stands
+ * where autograd sums the gradients a block input receives from its consumers -- the first RAB of a ResGroup, the group's skip
+ * connection (sradsgan.py:286-324) and the trunk's dense-sampling bus (:455-460) --: the data gradient that is computed last takes
+ * the other two in its epilogue instead of two element-wise add passes over 24 MB tensors per group.  Where the launch is served by a
+ * kernel without the extra operands (other arithmetic modes, small shapes) the library adds them with one srhip_sum_n pass, same order. */
+int srhip_conv2d_dgrad_res3(const float* dy, const float* packed, float* dx, const float* residual, const float* residual2,
+                            const float* residual3, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
+                            void* stream);
+int srhip_conv2d_dgrad_pp_res3(const void* dy, int dy_pp, const float* packed, float* dx, const float* residual, const float* residual2,
+                               const float* residual3, int n, int h, int w, int cin, int cout, void* stream);
 long srhip_pp_plane_pixels(int n, int h, int w);
 int srhip_pp_from_f32(const float* x_nhwc, void* pp, int n, int h, int w, int c, int ldx, void* stream);
 int srhip_pp_to_f32(const void* pp, float* x_nhwc, int n, int h, int w, int c, int ldx, void* stream);
@@ -299,8 +310,9 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
                         const float* fc2, float* du, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
                         int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
                         void* stream);
-/* ABI 9: the same, and the final du also as padded split-bf16 planes (du_pp; NULL: not wanted): the RAB's conv2 data and weight
- * gradient read it without a conversion pass */
+/* ABI 9: the same with the FINAL du as padded split-bf16 planes (du_pp) instead of the fp32 tensor: the RAB's conv2 data and weight
+ * gradient read the planes without a conversion pass.  `du` is then scratch (it holds the main pass's partial result, without the
+ * channel-pooling terms); du_pp NULL: exactly srhip_attn_tail_bwd. */
 int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
                         const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
                         const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,

@@ -441,7 +441,7 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
                                     int pix_blocks, const float* __restrict__ pw1, const float* __restrict__ pw2,
                                     float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden, int accfc,
                                     unsigned* __restrict__ du_pp = nullptr, int wd = 0, int guard = 0) {
-  // du_pp (round 5): the final du also leaves as padded split-bf16 planes (csrc/conv_wgrad_flat.hip: pixel row of 64 * 4 bytes,
+  // du_pp (round 5): the final du leaves as padded split-bf16 planes instead of fp32 (csrc/conv_wgrad_flat.hip: pixel row of 64 * 4 bytes,
   // per 8 channels 8 hi | 8 lo halves): the RAB's conv2 data gradient and weight gradient read it without a conversion pass
   if ((int)blockIdx.x >= pix_blocks) {
     const int i = ((int)blockIdx.x - pix_blocks) * blockDim.x + threadIdx.x;
@@ -468,8 +468,9 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
   d.y += ga.y * inv + (am.y == p ? gm.y : 0.f);
   d.z += ga.z * inv + (am.z == p ? gm.z : 0.f);
   d.w += ga.w * inv + (am.w == p ? gm.w : 0.f);
-  *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = d;
-  if (du_pp != nullptr) {
+  if (du_pp == nullptr) {                               // (with planes wanted the fp32 tensor stays the main pass's partial result: 24 MB less written per tail)
+    *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = d;
+  } else {
     const int y = p / wd, x = p - y * wd;
     const long row = guard + ((long)b * (hw / wd + 1) + y) * (wd + 1) + x;
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -999,7 +1000,8 @@ int srhip_attn_tail_bwd(const float* dz, const float* u, const float* s, const f
   return srhip_attn_tail_bwd_pp(dz, u, s, m, pooled, argc, avg, mx, argmax_hw, w7, fc1, fc2, du, nullptr, dw7, accumulate_dw7, dfc1, dfc2,
                                 accumulate_dfc, workspace, workspace_bytes, n, h, w, c, hidden, stream);
 }
-/* ABI 9: the same, and du also as padded split-bf16 planes in du_pp (NULL: not wanted) */
+/* ABI 9: the same with the final du as padded split-bf16 planes in du_pp INSTEAD of the fp32 tensor (du then only holds the main pass's
+ * partial result: scratch for the caller); du_pp NULL: srhip_attn_tail_bwd */
 int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
                            const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
                            const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,

@@ -394,6 +394,45 @@ int srhip_conv2d_dgrad(const float* dy, const float* packed, float* dx, const fl
   return legacy_conv2d_dgrad(dy, packed, dx, n, h, w, cin, cout, kh, kw, stride, pad, ldy, ldx, accumulate, stream);
 }
 
+/* ABI 9: the data gradient with up to THREE residuals, dx = conv_transpose(dy, w) + residual + residual2 + residual3 (in this order):
+ * a block input's gradient collects the block's own skip gradient and the gradients of the input's other consumers (the ResGroup's
+ * skip, the trunk's bus: sradsgan.py:286-324, 455-460) in the epilogue of the data gradient that is computed last, instead of the
+ * two element-wise passes autograd would add.  Contiguous rows only (ldx == ldr == cin).  The persistent patch kernel takes the extra
+ * residuals in its epilogue; where another kernel serves the shape / arithmetic mode, one srhip_sum_n pass adds them in the same order. */
+static int add_unserved_residuals(float* dx, const float* r2, const float* r3, long count, void* stream) {
+  const float* tab[3] = {dx, r2 ? r2 : r3, r3};
+  const int k = 1 + (r2 ? 1 : 0) + (r3 ? 1 : 0);
+  if (k == 1) return SRHIP_OK;
+  return srhip_sum_n(tab, k, dx, count, stream);
+}
+int srhip_conv2d_dgrad_res3(const float* dy, const float* packed, float* dx, const float* residual, const float* residual2,
+                            const float* residual3, int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
+                            void* stream) {
+  SRHIP_REQUIRE(residual && (residual2 || residual3), "conv2d_dgrad_res3: residual and at least one more");
+  SRHIP_REQUIRE(cin % 4 == 0 && ((((uintptr_t)residual2) | ((uintptr_t)residual3) | ((uintptr_t)dx)) & 15) == 0, "conv2d_dgrad_res3: Cin % 4 == 0, 16-byte aligned tensors");
+  g_res_req.r2 = residual2 ? residual2 : residual3;
+  g_res_req.r3 = residual2 ? residual3 : nullptr;
+  g_res_req.served = 0;
+  const int rc = srhip_conv2d_dgrad(dy, packed, dx, residual, nullptr, 0.f, n, h, w, cin, cout, kh, kw, stride, pad, cout, cin, cin, 0, stream);
+  const bool served = g_res_req.served != 0;
+  g_res_req = ResRequest();
+  if (rc != SRHIP_OK || served) return rc;
+  return add_unserved_residuals(dx, residual2, residual3, (long)n * h * w * cin, stream);
+}
+int srhip_conv2d_dgrad_pp_res3(const void* dy, int dy_pp, const float* packed, float* dx, const float* residual, const float* residual2,
+                               const float* residual3, int n, int h, int w, int cin, int cout, void* stream) {
+  SRHIP_REQUIRE(residual && (residual2 || residual3), "conv2d_dgrad_pp_res3: residual and at least one more");
+  SRHIP_REQUIRE(cin % 4 == 0 && ((((uintptr_t)residual2) | ((uintptr_t)residual3)) & 15) == 0, "conv2d_dgrad_pp_res3: Cin % 4 == 0, 16-byte aligned tensors");
+  g_res_req.r2 = residual2 ? residual2 : residual3;
+  g_res_req.r3 = residual2 ? residual3 : nullptr;
+  g_res_req.served = 0;
+  const int rc = srhip_conv2d_dgrad_pp(dy, dy_pp, packed, dx, 0, residual, nullptr, 0.f, n, h, w, cin, cout, stream);
+  const bool served = g_res_req.served != 0;
+  g_res_req = ResRequest();
+  if (rc != SRHIP_OK || served) return rc;
+  return add_unserved_residuals(dx, residual2, residual3, (long)n * h * w * cin, stream);
+}
+
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 size_t srhip_conv2d_wgrad_workspace(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {

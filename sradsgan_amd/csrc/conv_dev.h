@@ -29,7 +29,18 @@ struct FastGeom {
   // the attention tail's 1x1 conv leaves the next block's input x in both forms); NULL: not wanted
   void* dst2_pp = nullptr;
   int dst2_guard = 0;
+  // two MORE residuals of the destination's geometry (row stride ldr), added after `residual` in this order: the gradients a block
+  // input collects from its other consumers (group skip, trunk bus), folded into the data gradient that is computed last instead of
+  // two element-wise add passes (persistent patch kernel with an fp32 destination only; NULL: none)
+  const float* res2 = nullptr;
+  const float* res3 = nullptr;
 };
+struct ResRequest {                 // rides beside ONE data-gradient call (conv_api.hip: srhip_conv2d_dgrad_res3 / _pp_res3)
+  const float* r2 = nullptr;
+  const float* r3 = nullptr;
+  int served = 0;
+};
+extern thread_local ResRequest g_res_req;
 struct Dst2Request {                // rides beside ONE srhip_conv2d_fwd call (conv_api.hip: srhip_conv2d_fwd_dual), like PoolRequest
   void* pp = nullptr;
   int served = 0;

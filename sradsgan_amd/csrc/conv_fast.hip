@@ -2464,6 +2464,7 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
 }
 
 thread_local Dst2Request g_dst2_req;
+thread_local ResRequest g_res_req;
 int g_conv_math = 0;     // SRHIP_MATH_*: 0 exact fp32 MFMA; 1 split-bf16 x3 MFMA; 2 one 16-bit product (fp16 activations / bf16 gradients)
 int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
@@ -2880,6 +2881,10 @@ int fast_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* d
     g.dst_plane_bytes = (unsigned)(ppx * cin * 2L);
   }
   g.w_bytes = (unsigned)((long)cin * g.ldw * 4);
+  if (residual && !dx_pp) {                           // srhip_conv2d_dgrad_pp_res3: the kernel that takes them marks the request served
+    g.res2 = g_res_req.r2;
+    g.res3 = g_res_req.r3;
+  }
   return run_fast(static_cast<const float*>(dy), packed, nullptr, residual, nullptr, nullptr, static_cast<const float*>(actmask),
                   static_cast<float*>(dx), g, st);
 }
@@ -2899,6 +2904,10 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
   g.dst_identity = stride == 1 ? 1 : 0;
   SRHIP_REQUIRE(bytes_ok((long)n * ho * wo, ldy, cout, &g.src_bytes), "conv2d_dgrad: dy tensor >= 2 GiB");
   g.w_bytes = (unsigned)((long)cin * g.ldw * 4);
+  if (residual && stride == 1 && !accumulate) {       // srhip_conv2d_dgrad_res3: the kernel that takes them marks the request served
+    g.res2 = g_res_req.r2;
+    g.res3 = g_res_req.r3;
+  }
   // dx[hh] gathers dy[(hh + pad - kh)/stride] for kh == (hh + pad) mod stride: one dense GEMM per phase
   for (int ph = 0; ph < stride; ++ph) {
     for (int pw = 0; pw < stride; ++pw) {

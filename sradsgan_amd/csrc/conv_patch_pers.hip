@@ -478,6 +478,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
           const unsigned dpix = (doff >> 2) / (unsigned)g.ldd;      // (rare epilogue: the residual has its own row stride)
           const float4 r4 = *reinterpret_cast<const float4*>(residual + (size_t)dpix * g.ldr + ns);
           v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          if (g.res2 != nullptr) {                       // the block input's other gradients (FastGeom::res2 / res3), in this order
+            const float4 e4 = *reinterpret_cast<const float4*>(g.res2 + (size_t)dpix * g.ldr + ns);
+            v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
+          }
+          if (g.res3 != nullptr) {
+            const float4 e4 = *reinterpret_cast<const float4*>(g.res3 + (size_t)dpix * g.ldr + ns);
+            v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
+          }
         }
         const unsigned eoff = (ok && !(ABL & 1)) ? doff : F_OOB + ((ABL & 1) ? 16u * (unsigned)(p * NRD + i) : 0u);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_d, eoff, 0, 2);   // aux 2 = nt
@@ -732,6 +740,7 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
     const int pgrid = g_pers_grid > 0 ? (int)(g_pers_grid < ntiles ? g_pers_grid : ntiles) : (int)(ntiles < slots ? ntiles : slots);
 #define SRHIP_PPX(BN_, EPI_, POOL_, SRC_, DST_, PO_, PS_)                                                                        \
   do {                                                                                                                           \
+    if ((g.res2 || g.res3) && !(DST_)) g_res_req.served = 1;                                                                     \
     hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, 0, 0, POOL_, SRC_, DST_>), dim3(pgrid), dim3(256), 0, st, src, wsplit, bias, \
                        residual, actmask, dst, g, pg, nbm, nbn, pdbu, ndst16, PO_, PS_);                                         \
     return check_launch("conv_patch_pers_pp");                                                                                   \
@@ -790,6 +799,7 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
   const unsigned db = (unsigned)dbytes;
 #define SRHIP_PP(BN_, EPI_, PROD_)                                                                                      \
   do {                                                                                                                  \
+    if (g.res2 || g.res3) g_res_req.served = 1;                                                                         \
     hipLaunchKernelGGL((conv_patch_pers_kernel<BN_, EPI_, PROD_>), dim3(grid), dim3(256), 0, st, src, wsplit, bias,     \
                        residual, actmask, dst, g, pg, nbm, nbn, db, ndst16, nullptr, 0u);                                                    \
     return check_launch("conv_patch_pers");                                                                             \

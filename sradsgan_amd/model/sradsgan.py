@@ -155,6 +155,9 @@ class ResGroup(nn.Module, _AttentionTail):
         self._build_tail(rla_mode, pool_mode, nc, addconv)
 
     def forward(self, x):
+        first = self.RG[0]
+        if isinstance(first, RAB) and first._fusable(x):
+            ops.carry_open(x)          # x's other consumers (this group's skip, the trunk's bus) stash their gradients for the first RAB's backward
         return self._tail(self.RG(x), x)
 
 

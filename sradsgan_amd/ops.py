@@ -34,6 +34,9 @@ class _State:
     pending = None                  # shape key -> [(x, dy, gw, gb, stride, pad)] waiting for partners (direct_param_grads mode)
     held = None                     # gradients kept referenced until the backward ends, see _passed_through
     last_out_pp = None              # _RabBlock.forward -> rab_block(): the output's padded planes (emit_pp)
+    carry = None                    # token -> [gradients stashed for a block input by its other consumers] (carry_open)
+    carry_expect = None             # token -> number of consumers that committed to stash at forward time
+    carry_token = 0
 
 
 _state = _State()
@@ -121,6 +124,57 @@ def _passed_through(g):
     if _HOLD and _state.wgrad_stream is not None and _state.held is not None and g is not None:
         _state.held.append(g)
     return g
+
+
+_CARRY = os.environ.get('SRHIP_CARRY', '1') == '1'          # A/B knob: 0 = autograd sums the gradients of a group input (two add passes per group)
+
+
+def carry_open(x):
+    """Called by a consumer structure (model.ResGroup) on a block input `x` whose FIRST consumer is a fused RAB (rab_block): the input's
+    other consumers -- the group's skip connection (attention_tail) and the trunk's bus (sum_tensors) -- then do not hand their gradient
+    to autograd (which would add the three contributions with two element-wise passes over the 24 MB tensor) but stash it, and the RAB's
+    conv1 data gradient, computed last, takes them as extra residuals of its epilogue (srhip_conv2d_dgrad_res3 / _pp_res3).  The order of
+    the backward makes this safe: the RAB's backward depends on the group tail's, and the whole trunk's on the bus's; it is CHECKED:
+    the RAB counts the stashes it finds against the consumers that committed at forward time and raises when one is missing.
+    The tag travels as an attribute of the tensor object (a fresh token per call: no stale matches)."""
+    if not _CARRY or not x.is_cuda or not (torch.is_grad_enabled() and x.requires_grad):
+        return
+    if _state.carry is None or len(_state.carry_expect) > 4096:     # (forwards that never ran a backward leave their counters behind)
+        _state.carry, _state.carry_expect = {}, {}
+    _state.carry_token += 1
+    x._srhip_carry = _state.carry_token
+    _state.carry_expect[_state.carry_token] = 0
+
+
+def _carry_commit(t):
+    """forward time, a consumer that can stash: returns the token it will stash under (None: the tensor carries no tag)."""
+    token = getattr(t, '_srhip_carry', None) if _CARRY else None
+    if token is None or _state.carry_expect is None or token not in _state.carry_expect or not (torch.is_grad_enabled() and t.requires_grad):
+        return None
+    _state.carry_expect[token] += 1
+    return token
+
+
+def _carry_stash(token, g):
+    """backward time: True = `g` is stashed for the RAB (return None to autograd), False = hand it to autograd as usual."""
+    if token is None or token not in _state.carry_expect:
+        return False
+    if torch.is_grad_enabled():                                  # a differentiable backward: autograd must see the edge
+        _state.carry_expect[token] -= 1
+        return False
+    _state.carry.setdefault(token, []).append(g)
+    return True
+
+
+def _carry_take(token):
+    if token is None or _state.carry_expect is None:
+        return ()
+    extras = _state.carry.pop(token, [])
+    expect = _state.carry_expect.pop(token, 0)
+    if len(extras) != expect:
+        raise RuntimeError('rab_block backward: %d of %d gradients of the block input have arrived -- a consumer that committed to '
+                           'stash its gradient (ops.carry_open) has not run its backward yet' % (len(extras), expect))
+    return tuple(extras)
 
 
 def _grad_slot(p):
@@ -396,9 +450,10 @@ def conv2d_fwd_pool_raw(x, w, bias):
     return y, (pool, sec, nseg.value)
 
 
-def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, slope=0.0):
-    """dx = conv_transpose(dy, w) [* lrelu'(actmask)] [+ residual]: the optional tail fuses the backward
-    of the LeakyReLU that produced this conv's input and the skip-path gradient add."""
+def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, slope=0.0, extra=()):
+    """dx = conv_transpose(dy, w) [* lrelu'(actmask)] [+ residual] [+ extra[0] + extra[1]]: the optional tail fuses the backward
+    of the LeakyReLU that produced this conv's input and the skip-path gradient add; `extra`: up to two more gradients of dx's
+    shape (ops.carry_open), added after the residual in the order given."""
     _require_gpu(dy, 'conv2d_dgrad')
     dy = nhwc(dy)
     n, cin, h, wd = x_shape
@@ -409,6 +464,14 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride, pad, residual=None, actmask=None, s
     if actmask is not None:
         actmask = nhwc(actmask)
     lib = _hip.lib()
+    if extra:
+        if residual is None or actmask is not None or len(extra) > 2:
+            raise ValueError('conv2d_dgrad: extra residuals ride beside a residual, without an activation mask, at most two')
+        extra = [nhwc(e) for e in extra]
+        _hip.check(lib.srhip_conv2d_dgrad_res3(_p(dy), _p(packed_weight(w, 1)), _p(dx), _p(residual), _p(extra[0]),
+                                               _p(extra[1]) if len(extra) > 1 else None, n, h, wd, cin, cout, kh, kw, stride, pad,
+                                               _stream()), 'conv2d_dgrad_res3')
+        return dx
     _hip.check(lib.srhip_conv2d_dgrad(_p(dy), _p(packed_weight(w, 1)), _p(dx), _p(residual), _p(actmask), float(slope),
                                       n, h, wd, cin, cout, kh, kw, stride, pad, cout, cin, cin, 0, _stream()),
                'conv2d_dgrad')
@@ -579,7 +642,7 @@ def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
     return (y, (pl, sec, nseg.value)) if pool else y
 
 
-def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=None):
+def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=None, extra=()):
     """3x3 stride-1 pad-1 data gradient with padded-plane operands: dy a PP or fp32 NHWC; out_pp = PP buffer to fill, with
     actmask = the PP of the LeakyReLU output that fed the forward conv; or fp32 result (+ residual)."""
     cout, cin = w.shape[0], w.shape[1]
@@ -592,6 +655,14 @@ def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=No
     dx = out_pp if out_pp is not None else torch.empty(n, h, wd, cin, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
     if residual is not None:
         residual = nhwc(residual)
+    if extra:                                             # (ops.carry_open) up to two more gradients, added after the residual in this order
+        if residual is None or actmask is not None or out_pp is not None or len(extra) > 2:
+            raise ValueError('conv2d_dgrad_pp: extra residuals ride beside a residual of an fp32 destination, at most two')
+        extra = [nhwc(e) for e in extra]
+        _hip.check(_hip.lib().srhip_conv2d_dgrad_pp_res3(ctypes.c_void_p(dy.data_ptr()), int(ypp), _p(packed_weight(w, 1)), _p(dx), _p(residual),
+                                                         _p(extra[0]), _p(extra[1]) if len(extra) > 1 else None, n, h, wd, cin, cout,
+                                                         _stream()), 'conv2d_dgrad_pp_res3')
+        return dx
     _hip.check(_hip.lib().srhip_conv2d_dgrad_pp(ctypes.c_void_p(dy.data_ptr()), int(ypp), _p(packed_weight(w, 1)), ctypes.c_void_p(dx.data_ptr()),
                                                 int(out_pp is not None), _p(residual), ctypes.c_void_p(actmask.data_ptr()) if actmask is not None else None,
                                                 float(slope), n, h, wd, cin, cout, _stream()), 'conv2d_dgrad_pp')
@@ -1056,18 +1127,19 @@ class _SumN(Function):
     """((t0 + t1) + t2) + ... in one pass (srhip_sum_n); every term gets the incoming gradient, as with chained adds."""
 
     @staticmethod
-    def forward(ctx, *ts):
+    def forward(ctx, tokens, *ts):
         _require_gpu(ts[0], 'sum_n')
         ts = [nhwc(t) for t in ts]
         out = torch.empty_like(ts[0], memory_format=CL)
         tab = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         _hip.check(_hip.lib().srhip_sum_n(tab, len(ts), _p(out), out.numel(), _stream()), 'sum_n')
-        ctx.n = len(ts)
+        ctx.n, ctx.tokens = len(ts), tokens
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) * ctx.n
+        # a term that is the tagged input of a fused RAB (carry_open) gets no gradient edge: the RAB's data gradient adds g itself
+        return (None,) + tuple(None if _carry_stash(tok, g) else g for tok in ctx.tokens)
 
 
 def sum_tensors(ts):
@@ -1075,7 +1147,7 @@ def sum_tensors(ts):
     ts = list(ts)
     if (_BUS_SUM and 2 <= len(ts) <= 16 and ts[0].is_cuda and ts[0].dim() == 4 and ts[0].numel() % 4 == 0
             and all(t.shape == ts[0].shape and t.dtype == torch.float32 for t in ts)):
-        return _SumN.apply(*ts)
+        return _SumN.apply(tuple(_carry_commit(t) for t in ts), *ts)
     out = ts[0]
     for t in ts[1:]:
         out = out + t
@@ -1152,8 +1224,8 @@ def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None, out_pp=None):
 
 
 def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=False, du_pp=None):
-    """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc).  du_pp: a PP buffer that also receives du
-    as padded planes (fused path only; the caller checks `_TAIL_FUSED`)."""
+    """g: gradient at the tail's output (NHWC).  Returns (du, dfc1, dfc2, dw7, dwc, dbc).  du_pp: a PP buffer that receives du as
+    padded planes INSTEAD of the fp32 tensor (du is then returned as None; fused path only: the caller checks `_TAIL_FUSED`)."""
     avg, mx, arg, s, pooled, argc, m = saved
     n, c, h, w = u.shape
     lib = _hip.lib()
@@ -1194,6 +1266,8 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
         dw7 = None
     if direct:
         dfc1 = dfc2 = None
+    if du_pp is not None:
+        du = None                  # the fp32 tensor only holds the main pass's partial result: the planes are the gradient
     return du, dfc1, dfc2, dw7, dwc, dbc
 
 
@@ -1226,12 +1300,13 @@ def _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
 
 class _AttentionTail(Function):
     @staticmethod
-    def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc):
+    def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc, carry=None):
         _require_gpu(u, 'attention_tail')
         u, skip = nhwc(u), nhwc(skip)
         out, saved = _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc)
         ctx.save_for_backward(u, fc1_w, fc2_w, w7, wc, bc, *saved)
         ctx.has_bias = bc is not None
+        ctx.carry = carry              # token of a skip tensor whose gradient is stashed for the group's first RAB (carry_open)
         return out
 
     @staticmethod
@@ -1240,7 +1315,8 @@ class _AttentionTail(Function):
         g = nhwc(g)
         du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_bias,
                                                        _skip_param_grads())
-        return du, _passed_through(g), dfc1, dfc2, dw7, dwc, dbc
+        dskip = None if _carry_stash(ctx.carry, g) else _passed_through(g)
+        return du, dskip, dfc1, dfc2, dw7, dwc, dbc, None
 
 
 class _RabBlock(Function):
@@ -1251,9 +1327,10 @@ class _RabBlock(Function):
     gradient-accumulation adds, 3 saved activations (x, t, u) instead of ~12."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp=None, emit_pp=False):
+    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp=None, emit_pp=False, carry=None):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
+        ctx.carry = carry              # token under which the input's other consumers stash their gradients (carry_open)
         ctx.t_pp = ctx.x_pp = None
         _state.last_out_pp = None
         if rab_planes_ok(x, w1, w2):
@@ -1296,10 +1373,10 @@ class _RabBlock(Function):
         dw2 = db2 = dw1 = db1 = None
         if not skip:
             dw2, db2 = wgrad_for_params(w2, b2, t, du, 1, 1, ctx.has_b[1])
-        dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g) if ctx.needs_input_grad[0] else None   # + skip gradient
+        dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None   # + skip gradient (+ the input's stashed gradients)
         if not skip:
             dw1, db1 = wgrad_for_params(w1, b1, x, dt, 1, 1, ctx.has_b[0])
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None
 
     @staticmethod
     def _backward_planes(ctx, g):
@@ -1325,8 +1402,8 @@ class _RabBlock(Function):
             t_done = wgrad_pp_for_params(w2, b2, t_pp, du_pp if du_pp is not None else du, ctx.has_b[1],
                                          release=(t_pp,) if du_pp is None else (t_pp, du_pp))
             if not t_done:                                # autograd wants the gradients returned: the fp32 path on converted operands
-                dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du, 1, 1, ctx.has_b[1])
-        dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g) if ctx.needs_input_grad[0] else None   # + skip gradient
+                dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du if du is not None else pp_to_f32(du_pp), 1, 1, ctx.has_b[1])
+        dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None   # + skip gradient (+ the input's stashed gradients)
         if not skip:
             dt_done = wgrad_pp_for_params(w1, b1, x_pp if x_pp is not None else x, dt_pp, ctx.has_b[0],
                                           release=(dt_pp,) if x_pp is None else (dt_pp, x_pp))
@@ -1340,7 +1417,7 @@ class _RabBlock(Function):
             plane_pool.put(dt_pp, (main,))
             if x_pp is not None:
                 plane_pool.put(x_pp, (main,))
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None
 
 
 def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
@@ -1369,7 +1446,7 @@ def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
     tag = getattr(x, '_srhip_pp', None) if _X_PP else None
     if tag is not None and tag[1] == x._version and tag[0].shape == tuple(x.shape):
         x_pp = tag[0]
-    out = _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp, bool(emit_pp and _X_PP))
+    out = _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp, bool(emit_pp and _X_PP), getattr(x, '_srhip_carry', None) if _CARRY else None)
     pp, _state.last_out_pp = getattr(_state, 'last_out_pp', None), None
     if pp is not None:
         out._srhip_pp = (pp, out._version)
@@ -1386,7 +1463,7 @@ def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc):
     if _tail_eval_ok(u):
         _require_gpu(u, 'attention_tail')
         return _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc)
-    return _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc)
+    return _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc, _carry_commit(skip))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -180,3 +180,35 @@ def test_rab_chain_with_handed_over_input_planes_is_bit_identical():
             res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blocks.parameters()])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', [(32, 54, 54), (16, 54, 54), (2, 23, 37), (1, 9, 20)])
+@pytest.mark.parametrize('nextra', [1, 2])
+def test_data_gradient_with_three_residuals_equals_the_chained_adds(case, nextra):
+    """srhip_conv2d_dgrad_res3 / _pp_res3 (ABI 9): dx = dgrad + residual + residual2 + residual3 in that order -- the persistent patch
+    kernel's epilogue at the bench shapes, one srhip_sum_n pass where another kernel serves the launch -- against the plain call
+    followed by torch adds in the same order: bit-identical (each add is one fp32 rounding either way)."""
+    from sradsgan_amd import ops
+    n, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + 77 + nextra)
+    dt = _cl(torch.randn(n, 256, h, w, generator=g))
+    w1 = torch.nn.Parameter((torch.randn(256, 64, 3, 3, generator=g) * 0.05).to(DEV))
+    res = _cl(torch.randn(n, 64, h, w, generator=g))
+    extra = [_cl(torch.randn(n, 64, h, w, generator=g)) for _ in range(nextra)]
+    with ops.conv_math('bf16x3'):
+        want = ops.conv2d_dgrad_raw(dt, w1, (n, 64, h, w), 1, 1, res)
+        for e in extra:
+            want = want + e
+        got = ops.conv2d_dgrad_raw(dt, w1, (n, 64, h, w), 1, 1, res, extra=extra)
+        assert torch.equal(got, want)
+        dt_pp = ops.pp_from_f32(dt)
+        want_pp = ops.conv2d_dgrad_pp_raw(dt_pp, w1, residual=res)
+        for e in extra:
+            want_pp = want_pp + e
+        got_pp = ops.conv2d_dgrad_pp_raw(dt_pp, w1, residual=res, extra=extra)
+        assert torch.equal(got_pp, want_pp)
+    with ops.conv_math('fp32'):                          # another kernel family: the library adds the extras itself
+        want = ops.conv2d_dgrad_raw(dt, w1, (n, 64, h, w), 1, 1, res)
+        for e in extra:
+            want = want + e
+        assert torch.equal(ops.conv2d_dgrad_raw(dt, w1, (n, 64, h, w), 1, 1, res, extra=extra), want)

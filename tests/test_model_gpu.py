@@ -632,3 +632,48 @@ def test_conv_epilogue_pooling_partials_match_the_pooling_pass(shape):
         finally:
             lib.srhip_debug_set(0, 0)
             lib.srhip_debug_set(5, 0)
+
+
+def test_group_input_gradients_folded_into_the_first_rab_match_autograd_sums():
+    """ops.carry_open (round 5): a ResGroup input's gradients from the group skip and the trunk's bus are stashed and added by the
+    first RAB's conv1 data gradient (srhip_conv2d_dgrad_res3) instead of two autograd add passes.  Same graph with the mechanism
+    off (autograd sums): every gradient agrees to fp32 summation-order roundoff, nothing stays stashed, and the mechanism was used."""
+    from sradsgan_amd import model as M, ops
+    torch.manual_seed(11)
+    net = M.GeneratorResNet(M.ResGroup, n_residual_blocks=3, n_basic_blocks=2, upscale_factor=2).to(DEV)
+    x = torch.rand(2, 3, 24, 20, device=DEV)
+    dy = torch.randn(2, 3, 48, 40, device=DEV)
+
+    def run(carry):
+        old, ops._CARRY = ops._CARRY, carry
+        try:
+            for p in net.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            t0 = ops._state.carry_token
+            net(xi).backward(dy)
+            return xi.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}, ops._state.carry_token - t0
+        finally:
+            ops._CARRY = old
+
+    dx1, g1, used1 = run(True)
+    assert used1 == 3 and not ops._state.carry and not ops._state.carry_expect        # three groups, everything consumed
+    dx0, g0, used0 = run(False)
+    assert used0 == 0
+    _close(dx1.cpu(), dx0.cpu(), tol=1e-5, msg='dx')
+    for k in g0:
+        _close(g1[k].cpu(), g0[k].cpu(), tol=2e-5, msg=k)
+
+
+def test_a_missing_stash_is_an_error_not_a_wrong_gradient():
+    """The first RAB counts the stashed gradients against the consumers that committed at forward time: one missing raises."""
+    from sradsgan_amd import model as M, ops
+    grp = M.ResGroup(M.RAB, n_blocks=1).to(DEV)
+    x = torch.rand(1, 64, 12, 12, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = grp(x * 1.0)
+    assert len(ops._state.carry_expect) >= 1
+    tok = max(ops._state.carry_expect)
+    ops._state.carry_expect[tok] += 1                 # a consumer that committed and never ran
+    with pytest.raises(RuntimeError, match='gradients of the block input'):
+        y.sum().backward()
+    ops._state.carry.clear(); ops._state.carry_expect.clear()
