@@ -1920,7 +1920,23 @@ def batch_norm_act(x, bn, slope=None):
 
 def replay_bn_update(stash):
     """Applies nn.BatchNorm2d's running-statistics update once more for every stashed (bn, mean, invstd, n)."""
+    if not stash:
+        return
     with torch.no_grad():
+        if len({(bn.momentum, bn.eps) for bn, _, _, _ in stash}) == 1 and len(stash) > 1:
+            # one launch per arithmetic step for all layers (the same element-wise operations as the per-layer form below)
+            bn0 = stash[0][0]
+            m, eps = bn0.momentum, bn0.eps
+            var = torch._foreach_pow([t[2] for t in stash], -2)
+            torch._foreach_sub_(var, eps)
+            torch._foreach_mul_(var, [n / max(n - 1, 1) for _, _, _, n in stash])
+            rm, rv = [t[0].running_mean for t in stash], [t[0].running_var for t in stash]
+            torch._foreach_mul_(rm, 1 - m)
+            torch._foreach_add_(rm, [t[1] for t in stash], alpha=m)
+            torch._foreach_mul_(rv, 1 - m)
+            torch._foreach_add_(rv, var, alpha=m)
+            torch._foreach_add_([t[0].num_batches_tracked for t in stash], 1)
+            return
         for bn, mean, invstd, n in stash:
             var = invstd.pow(-2) - bn.eps
             bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
