@@ -126,6 +126,7 @@ extern int g_sgam_cfg;
 extern int g_pers_grid;
 extern int g_pers_small;
 extern int g_pers_abl;
+extern int g_phase_batch;
 }
 extern int g_tail_dbg;
 namespace srhip {
@@ -260,6 +261,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 16) {
     g_patch8_abl = value;
+    return SRHIP_OK;
+  }
+  if (key == 17) {
+    g_phase_batch = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -41,6 +41,21 @@ struct ResRequest {                 // rides beside ONE data-gradient call (conv
   int served = 0;
 };
 extern thread_local ResRequest g_res_req;
+// The stride^2 phases of a strided data gradient as ONE launch of fast_conv_dma_kernel (round 5): block ranges [first[k], first[k+1])
+// run phase k with its own virtual output grid and tap list.  Four quarter-filled launches of the discriminator's 14^2 / 27^2 layers
+// become one that fills the chip.  n = 0: a plain launch.
+struct PhaseSet {
+  int n = 0;
+  int first[5] = {0, 0, 0, 0, 0};
+  struct P {
+    int ph, pw, OH, OW, kh0, kw0, TH, TW, dh0, dw0, M, nblk_m;
+  } p[4];
+};
+struct PhaseRequest {               // rides beside the FIRST phase's run_fast call of fast_conv2d_dgrad; launched = 1: all phases are out
+  PhaseSet ps;
+  int active = 0, launched = 0;
+};
+extern thread_local PhaseRequest g_phase_req;
 struct Dst2Request {                // rides beside ONE srhip_conv2d_fwd call (conv_api.hip: srhip_conv2d_fwd_dual), like PoolRequest
   void* pp = nullptr;
   int served = 0;

@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
                                                              const float* __restrict__ rowscale,
                                                              const float* __restrict__ chanscale,
                                                              const float* __restrict__ actmask,
-                                                             float* __restrict__ dst, FastGeom g, int nblk_m,
-                                                             int nblk_n) {
+                                                             float* __restrict__ dst, FastGeom g_in, int nblk_m,
+                                                             int nblk_n, PhaseSet ps) {
   constexpr int WM = 2, WN = 2, BK = 16;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -415,7 +415,20 @@ __global__ __launch_bounds__(256) void fast_conv_dma_kernel(const float* __restr
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps per-wave control flow on the scalar unit
-  const int tile = xcd_tile(blockIdx.x, nblk_m * nblk_n);
+  FastGeom g = g_in;
+  int bid = blockIdx.x;
+  if (ps.n > 1) {                                      // the phases of a strided data gradient in one launch (PhaseSet, conv_dev.h)
+    int k = 0;
+    if (bid >= ps.first[1]) k = 1;
+    if (ps.n > 2 && bid >= ps.first[2]) k = 2;
+    if (ps.n > 3 && bid >= ps.first[3]) k = 3;
+    bid -= ps.first[k];
+    const PhaseSet::P q = ps.p[k];
+    g.ph = q.ph; g.pw = q.pw; g.OH = q.OH; g.OW = q.OW; g.kh0 = q.kh0; g.kw0 = q.kw0; g.TH = q.TH; g.TW = q.TW;
+    g.dh0 = q.dh0; g.dw0 = q.dw0; g.M = q.M;
+    nblk_m = q.nblk_m;
+  }
+  const int tile = xcd_tile(bid, nblk_m * nblk_n);
   const int tile_n = tile % nblk_n, tile_m = tile / nblk_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -2465,6 +2478,7 @@ int fast_pack_weight(const float* w, float* packed, int cout, int cin, int kh, i
 
 thread_local Dst2Request g_dst2_req;
 thread_local ResRequest g_res_req;
+thread_local PhaseRequest g_phase_req;
 int g_conv_math = 0;     // SRHIP_MATH_*: 0 exact fp32 MFMA; 1 split-bf16 x3 MFMA; 2 one 16-bit product (fp16 activations / bf16 gradients)
 int g_fast_dynlds = 0;   // experiment knob (srhip_debug_set(2, bytes)): extra dynamic LDS per block = occupancy limiter
 template <int BM, int BN, int WM, int WN, int BK>
@@ -2523,6 +2537,7 @@ __global__ __launch_bounds__(256) void dot_conv_kernel(const float* __restrict__
 // experiment knob (srhip_debug_set(0, cfg)): 0 = heuristic below
 int g_patch_ks = 1;    // srhip_debug_set(10, v): 0 = conv_patch_kernel<64> instead of conv_patch_ks_kernel (bit-identical to the DMA kernel; A/B and pinned tests)
 int g_fast_cfg = 0;
+int g_phase_batch = 1;   // srhip_debug_set(17, v): 1 = the phases of a stride-2 data gradient as one launch of the LDS-DMA kernel
 
 // Patch shape for conv_patch_kernel: PH x PW output pixels per block (<= 128), halo patch <= 192 rows = 12 DMA pieces; picks the
 // shape that wastes the fewest of the 128 GEMM rows over the whole image (halo patch <= 192 rows = 12 DMA pieces).  Only stride-1 3x3 geometries.
@@ -2723,6 +2738,8 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
     // fp32: the register-staged kernel wins below ~2 tiles per CU; split-bf16: its fp32 MFMAs cost 5x more than
     // the DMA kernel's, so the DMA kernel is taken from half a wave of tiles on
     const long min_tiles = g_conv_math >= 1 ? 128 : 512;
+    // (round 5, measured and dropped: 64-wide tiles for launches with fewer than 384 wide tiles -- D's 512 -> 512 stride-2 conv at 14 x 14,
+    // 196 -> 392 blocks -- ran 154.5 us against 143.8)
     const bool wide = g.K >= 128 && ((long)nbm * cdiv(g.K, 128) >= min_tiles || force);
     const long b64 = (long)nbm * cdiv(g.K, 64);
     if (wide || b64 >= min_tiles || force) {
@@ -2730,13 +2747,25 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   do {                                                                                                             \
     const int nbn = cdiv(g.K, BN_);                                                                                \
     if (g.dst2_pp) g_dst2_req.served = 1;                                                                          \
+    PhaseSet ps_;                                                                                                  \
+    int grid_ = nbm * nbn;                                                                                         \
+    if (g_phase_req.active) {                          /* all phases of a strided data gradient in this launch */  \
+      ps_ = g_phase_req.ps;                                                                                        \
+      grid_ = 0;                                                                                                   \
+      for (int k_ = 0; k_ < ps_.n; ++k_) {                                                                         \
+        ps_.first[k_] = grid_;                                                                                     \
+        grid_ += ps_.p[k_].nblk_m * nbn;                                                                           \
+      }                                                                                                            \
+      ps_.first[ps_.n] = grid_;                                                                                    \
+      g_phase_req.launched = 1;                                                                                    \
+    }                                                                                                              \
     if (g_conv_math == 1) {                                                                                        \
-      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 1>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
+      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 1>), dim3(grid_), dim3(256), g_fast_dynlds, st,     \
                          src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm,                      \
-                         nbn);                                                                                     \
+                         nbn, ps_);                                                                                \
     } else                                                                                                         \
-      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 0>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st, \
-                         src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                 \
+      hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, EPI_, 0>), dim3(grid_), dim3(256), g_fast_dynlds, st,     \
+                         src, wt, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn, ps_);            \
     return check_launch("fast_conv_dma");                                                                          \
   } while (0)
 #define SRHIP_LDE(BN_)                                                  \
@@ -2755,7 +2784,7 @@ static int run_fast(const float* src, const float* wt, const float* bias, const 
   do {                                                                                                              \
     const int nbn = cdiv(g.K, BN_);                                                                                 \
     hipLaunchKernelGGL((fast_conv_dma_kernel<128, BN_, -1, MATH_>), dim3(nbm * nbn), dim3(256), g_fast_dynlds, st,  \
-                       src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn);                   \
+                       src, w16, bias, residual, rowscale, chanscale, actmask, dst, g, nbm, nbn, PhaseSet());       \
     return check_launch("fast_conv_dma");                                                                           \
   } while (0)
         if (wide && prod == 1) SRHIP_LDH(128, 2);
@@ -2909,6 +2938,33 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
     g.res3 = g_res_req.r3;
   }
   // dx[hh] gathers dy[(hh + pad - kh)/stride] for kh == (hh + pad) mod stride: one dense GEMM per phase
+  // Round 5: where the LDS-DMA kernel takes the phases (split-bf16 / fp32 arithmetic), ALL of them go out as ONE launch (PhaseSet):
+  // the request rides beside the first phase's run_fast call, which launches every phase when it reaches that kernel.
+  PhaseRequest& pq = g_phase_req;
+  pq = PhaseRequest();
+  if (stride == 2 && g_conv_math != 2 && g_phase_batch) {          // (srhip_debug_set(17, 0): one launch per phase, rounds 1-4)
+    bool all = true;
+    int k = 0;
+    for (int ph = 0; ph < stride && all; ++ph)
+      for (int pw = 0; pw < stride && all; ++pw) {
+        PhaseSet::P& q = pq.ps.p[k++];
+        q.ph = ph; q.pw = pw;
+        q.OH = (h - ph + stride - 1) / stride;
+        q.OW = (w - pw + stride - 1) / stride;
+        q.kh0 = (ph + pad) % stride; q.kw0 = (pw + pad) % stride;
+        q.TH = q.kh0 < kh ? (kh - q.kh0 + stride - 1) / stride : 0;
+        q.TW = q.kw0 < kw ? (kw - q.kw0 + stride - 1) / stride : 0;
+        q.dh0 = (ph + pad - q.kh0) / stride; q.dw0 = (pw + pad - q.kw0) / stride;
+        const long M = (long)n * q.OH * q.OW;
+        all = q.OH > 0 && q.OW > 0 && q.TH > 0 && q.TW > 0 && M < (1L << 31);
+        q.M = (int)M;
+        q.nblk_m = cdiv(M, 128);
+      }
+    if (all) {
+      pq.ps.n = stride * stride;
+      pq.active = 1;
+    }
+  }
   for (int ph = 0; ph < stride; ++ph) {
     for (int pw = 0; pw < stride; ++pw) {
       g.ph = ph; g.pw = pw;
@@ -2924,7 +2980,10 @@ int fast_conv2d_dgrad(const float* dy, const float* packed, float* dx, const flo
       SRHIP_REQUIRE(M < (1L << 31), "conv2d_dgrad: pixel count overflows int32");
       g.M = (int)M;
       int rc = run_fast(dy, packed, nullptr, residual, nullptr, nullptr, actmask, dx, g, st);
+      const bool all_out = pq.active && pq.launched;
+      pq = PhaseRequest();                              // (a request only ever rides beside the first phase)
       if (rc) return rc;
+      if (all_out) return SRHIP_OK;
     }
   }
   return SRHIP_OK;

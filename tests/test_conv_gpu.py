@@ -651,3 +651,30 @@ def test_batched_repack_writes_the_bytes_of_the_single_pack(cout, cin, k):
         _hip.check(lib.srhip_pack_weights_batched(tab.data_ptr(), 1, None))
         torch.cuda.synchronize()
         assert torch.equal(one.view(torch.int32), many.view(torch.int32)), (mode, fast)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(32, 64, 64, 54, 54), (8, 128, 128, 54, 54), (32, 256, 256, 27, 27), (32, 512, 512, 14, 14), (3, 64, 128, 11, 13),
+                                  (2, 256, 256, 9, 9)])
+@pytest.mark.parametrize('math', ['bf16x3', 'fp32'])
+def test_stride2_data_gradient_phases_in_one_launch_are_bit_identical(case, math):
+    """Round 5: the four phases of a 3x3 stride-2 data gradient (the discriminator's blocks 2/4/6/8, sradsgan.py:476) go out as ONE
+    launch of the LDS-DMA kernel (PhaseSet) instead of four: same kernel, same arithmetic per tile -> same bits as the per-phase
+    launches (srhip_debug_set(17, 0)); x shapes with odd sizes (27 -> 14) have phases of different extents."""
+    from sradsgan_amd import ops, _hip
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda())
+    lib = _hip.lib()
+    with ops.conv_math(math):
+        try:
+            lib.srhip_debug_set(17, 0)
+            want = ops.conv2d_dgrad_raw(dy, wt, (n, cin, h, w), 2, 1)
+        finally:
+            lib.srhip_debug_set(17, 1)
+        got = ops.conv2d_dgrad_raw(dy, wt, (n, cin, h, w), 2, 1)
+    assert torch.equal(got, want)
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.detach().double(), dy.double(), stride=2, padding=1)
+    assert (got.double() - ref).abs().max() <= 2e-4 * ref.abs().max()
