@@ -443,6 +443,10 @@ int srhip_bn_train_bwd_bwd_acc(const float* ddx, const float* dy, const float* x
 int srhip_metric_blocks(void);
 int srhip_quant_sse(const float* a, const float* b, unsigned long long* partial, int n, long per_image, void* stream);
 int srhip_ssim_u8(const float* a, const float* b, double* partial, int n, int h, int w, int c, void* stream);
+/* ABI 9: the scalar tail of the two metric passes for all images in one launch: out = double [4][n], rows mse, psnr (inf where mse = 0),
+ * ssim, ergas (utils.py:923-962) */
+int srhip_metric_finish(const unsigned long long* sse_partial, const double* ssim_partial, double* out, int n, int h, int w, int c,
+                        double scale, void* stream);
 
 /* ---- torch.optim.Adam (sradsgan.py:724-725, step at :858 and :887) over a flat fp32 arena, fused
  *      with the discriminator's weight clip `p.data.clamp_(-c, c)` (:891-892; clip <= 0: none).

@@ -118,6 +118,7 @@ SIGNATURES = {
     'srhip_metric_blocks': (_i, []),
     'srhip_quant_sse': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'srhip_ssim_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_metric_finish': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_double, _vp]),
     'srhip_adam_step': (_i, [_vp] * 5 + [_l] + [_f] * 6 + [_vp]),
 }
 

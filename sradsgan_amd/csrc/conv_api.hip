@@ -127,6 +127,7 @@ extern int g_pers_grid;
 extern int g_pers_small;
 extern int g_pers_abl;
 extern int g_phase_batch;
+extern int g_headconv_rows;
 }
 extern int g_tail_dbg;
 namespace srhip {
@@ -265,6 +266,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 17) {
     g_phase_batch = value;
+    return SRHIP_OK;
+  }
+  if (key == 18) {
+    g_headconv_rows = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

@@ -19,6 +19,9 @@
 #include "common.h"
 
 namespace srhip {
+int g_headconv_rows = 4;   // srhip_debug_set(18, rows): image rows a block of headconv_fwd_kernel walks
+}
+namespace srhip {
 
 constexpr int BK = 16;
 
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
 __global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ packed,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             int N, int H, int W, int cin, int cout, int ldx, int ldy,
-                                                            int ldw, float slope, int flags) {
+                                                            int ldw, float slope, int flags, int rows_per_block) {
   extern __shared__ float xs[];                      // [3][W + 2][cin]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,8 +444,10 @@ __global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restri
     if (co0 + l31 < cout) b0 = bias[co0 + l31];
     if (co0 + 32 + l31 < cout) b1 = bias[co0 + 32 + l31];
   }
-  const int r = blockIdx.x;
+  // a block walks `rows_per_block` consecutive image rows: the 32 weight loads per lane and the tap offsets above are paid once
+  for (int r = blockIdx.x * rows_per_block; r < min((int)(blockIdx.x + 1) * rows_per_block, N * H); ++r) {
   const int n = r / H, oh = r - n * H;
+  __syncthreads();                                   // the previous row's gathers are done
   for (int e = tid; e < 3 * rowlen; e += 256) {
     const int kh = e / rowlen, rem = e - kh * rowlen;
     const int col = rem / cin, ci = rem - col * cin;
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restri
         if (co0 + 32 + l31 < cout) o[32] = v1;
       }
     }
+  }
   }
 }
 
@@ -821,8 +827,9 @@ int legacy_conv2d_fwd(const float* x, const float* packed, const float* bias, co
   g.M = (int)M; g.slope = slope; g.flags = flags; g.accumulate = 0;
   if (cin <= 3 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && M >= 65536 &&
       !(flags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU)) && (size_t)3 * (w + 2) * cin * sizeof(float) <= 32 * 1024) {
-    hipLaunchKernelGGL(headconv_fwd_kernel, dim3(n * h, cdiv(cout, 64)), dim3(256), (size_t)3 * (w + 2) * cin * sizeof(float),
-                       as_stream(stream), x, packed, bias, y, n, h, w, cin, cout, ldx, ldy, g.ldw, slope, flags);
+    const int rpb = g_headconv_rows > 0 ? g_headconv_rows : 1;
+    hipLaunchKernelGGL(headconv_fwd_kernel, dim3(cdiv((long)n * h, rpb), cdiv(cout, 64)), dim3(256), (size_t)3 * (w + 2) * cin * sizeof(float),
+                       as_stream(stream), x, packed, bias, y, n, h, w, cin, cout, ldx, ldy, g.ldw, slope, flags, rpb);
     return check_launch("headconv_fwd");
   }
   return run_fprop(x, packed, bias, residual, rowscale, y, g, as_stream(stream));
