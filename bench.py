@@ -278,9 +278,9 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         # pair launch + its reduce --, with the pair launch alone (operands already planes) next to it.
         # Operands: THREE sets of two convolutions each (750 MB), launched in rotation, so that no launch finds its operands in the
         # 256 MB Infinity Cache (in the step they were written tens of milliseconds earlier): one set alone reads 20 % faster.
-        # In the step a RAB's input x arrives as planes from the previous block's tail conv for two blocks of three
-        # (srhip_conv2d_fwd_dual); the first block of a ResGroup converts x with one pp_from_f32 pass on the weight-gradient stream:
-        # on average 2/3 of a pass per pair launch, which `frac` includes (`conversion_pass_ms`, `pair_launch_alone_*` without it).
+        # In the step a RAB's input x arrives as planes from the tail conv of the block (or, round 5's last change, of the GROUP) in front
+        # of it (srhip_conv2d_fwd_dual); only the very first RAB, fed by the head conv, converts x with one pp_from_f32 pass on the
+        # weight-gradient stream: one pass per 18 pair launches, which `frac` includes (`conversion_pass_ms`, `pair_launch_alone_*` without it).
         sets = []
         for k in range(3):
             xs_ = (x, x2) if k == 0 else (torch.randn_like(x), torch.randn_like(x))
@@ -293,16 +293,15 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
             rot[0] = (rot[0] + 1) % 3
             ops.conv2d_wgrad_pp_raw(sets[rot[0]])
 
-        def wgrad_pp():                                     # three pair launches + two conversion passes = the step's average mix
-            for _ in range(3):
+        def wgrad_pp():                                     # 18 pair launches + one conversion pass = the 36 conv1 weight gradients of one step
+            for _ in range(18):
                 pair_alone()
             ops.pp_from_f32(x, out=ppx_scratch)
-            ops.pp_from_f32(x2, out=ppx_scratch)
         wgrad_fn = wgrad_pp
-        wgrad_calls = 3                                     # pair launches per call of wgrad_fn
+        wgrad_calls = 18                                    # pair launches per call of wgrad_fn
         pitems = sets[0]
         kw_label = ('wgrad_flat8_kernel<dy planes 256 ch, x planes 64 ch> x2 convolutions per launch + reduce, operands cold (three sets in rotation), '
-                    '+ 2/3 pp_from_f32 pass of x per launch (the first block of a ResGroup)')
+                    '+ 1/18 pp_from_f32 pass of x per launch (the first RAB of the trunk)')
         if with_single:                                   # (not under the profiler: its per-kernel averages and byte counters then belong to the launch the step runs)
             wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(pair_alone, 300), 4)
             wgrad_extra['conversion_pass_ms'] = round(_time_launches(lambda: ops.pp_from_f32(x, out=ppx_scratch), 200), 4)

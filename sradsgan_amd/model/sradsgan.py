@@ -90,13 +90,13 @@ class _AttentionTail:
         if la_mode == '':
             self.last_conv = HipConv2d(64, 64, kernel_size=1, bias=True)
 
-    def _tail(self, out, skip):
+    def _tail(self, out, skip, emit_pp=False):
         """attention tail followed by `out += skip`; the add is fused into the closing 1x1 conv."""
         m = self.la_mode
         if (m == 'CA-SA' and self.addconv and self.ca.pool_mode == 'Avg|Max' and self.sa.pool_mode == 'Avg|Max'
                 and ops.attention_tail_supported(out, self.ca.fc1.weight, self.sa.conv1.weight, self.conv.weight)):
             return ops.attention_tail(out, skip, self.ca.fc1.weight, self.ca.fc2.weight, self.sa.conv1.weight,
-                                      self.conv.weight, self.conv.bias)
+                                      self.conv.weight, self.conv.bias, emit_pp=emit_pp)
         if m in ('CA-SA', 'SA-CA'):
             first, second = (self.ca, self.sa) if m == 'CA-SA' else (self.sa, self.ca)
             out = second(first(out))
@@ -158,7 +158,9 @@ class ResGroup(nn.Module, _AttentionTail):
         first = self.RG[0]
         if isinstance(first, RAB) and first._fusable(x):
             ops.carry_open(x)          # x's other consumers (this group's skip, the trunk's bus) stash their gradients for the first RAB's backward
-        return self._tail(self.RG(x), x)
+        nr = self.__dict__.get('_next_rab')            # the first RAB of the group this group feeds (GeneratorResNet.__init__), not a submodule
+        emit = nr is not None and nr._fusable(x) and ops.rab_planes_ok(x, nr.conv1.weight, nr.conv2.weight)
+        return self._tail(self.RG(x), x, emit_pp=emit)  # a group feeding a group: the output also as padded planes (ops.attention_tail)
 
 
 class MSB(nn.Module):
@@ -241,6 +243,10 @@ class GeneratorResNet(nn.Module):
             buildingblock(RAB, n_blocks=n_basic_blocks, nc=64, kernel_size=3, stride=1, padding=1,
                           act_type='lrelu', mode='CNA', rla_mode=rla_mode, bla_mode=bla_mode, pool_mode=pool_mode,
                           addconv=addconv) for _ in range(n_residual_blocks)])
+        groups = list(self.res_groups)
+        for grp, nxt in zip(groups[:-1], groups[1:]):        # a group whose output is the input of a group that starts with a RAB
+            if isinstance(grp, ResGroup) and isinstance(nxt, ResGroup) and isinstance(nxt.RG[0], RAB):
+                grp.__dict__['_next_rab'] = nxt.RG[0]        # (plain attribute: the block stays a submodule of ITS group only)
         self.GAB_UP = GAB_UP(ga_mode=ga_mode, addconv=addconv, upscale_factor=upscale_factor)
         self.MSB = MSB(inplanes=in_channels, planes=64)
         self.conv3 = nn.Sequential(HipConv2d(64, out_channels, 3, 1, 1))

@@ -1300,10 +1300,16 @@ def _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None):
 
 class _AttentionTail(Function):
     @staticmethod
-    def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc, carry=None):
+    def forward(ctx, u, skip, fc1_w, fc2_w, w7, wc, bc, carry=None, emit_pp=False):
         _require_gpu(u, 'attention_tail')
         u, skip = nhwc(u), nhwc(skip)
-        out, saved = _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc)
+        _state.last_out_pp = None
+        out_pp = None
+        if emit_pp:                                    # the output also as padded planes for the RAB that consumes it (attention_tail)
+            n, c, h, wd = u.shape
+            out_pp = plane_pool.get(n, c, h, wd, u.device)
+        out, saved = _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, out_pp=out_pp)
+        _state.last_out_pp = out_pp
         ctx.save_for_backward(u, fc1_w, fc2_w, w7, wc, bc, *saved)
         ctx.has_bias = bc is not None
         ctx.carry = carry              # token of a skip tensor whose gradient is stashed for the group's first RAB (carry_open)
@@ -1316,7 +1322,7 @@ class _AttentionTail(Function):
         du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_bias,
                                                        _skip_param_grads())
         dskip = None if _carry_stash(ctx.carry, g) else _passed_through(g)
-        return du, dskip, dfc1, dfc2, dw7, dwc, dbc, None
+        return du, dskip, dfc1, dfc2, dw7, dwc, dbc, None, None
 
 
 class _RabBlock(Function):
@@ -1458,12 +1464,20 @@ def attention_tail_supported(u, fc1_w, w7, wc):
             and tuple(wc.shape[:2]) == (64, 64))
 
 
-def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc):
-    """conv1x1(SLAM(CLAM(u))) + bc + skip  for la_mode 'CA-SA', pool 'Avg|Max', addconv, C = 64."""
+def attention_tail(u, skip, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
+    """conv1x1(SLAM(CLAM(u))) + bc + skip  for la_mode 'CA-SA', pool 'Avg|Max', addconv, C = 64.  emit_pp (the caller knows that a
+    fused RAB consumes the output: a ResGroup followed by a ResGroup): the 1x1 conv leaves the output also as padded planes, which
+    travel as an attribute of the output tensor like rab_block's -- the next group's first RAB and its weight gradient read them
+    instead of running a conversion pass."""
     if _tail_eval_ok(u):
         _require_gpu(u, 'attention_tail')
         return _tail_forward_eval(u, skip, fc1_w, fc2_w, w7, wc, bc)
-    return _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc, _carry_commit(skip))
+    emit = bool(emit_pp and _X_PP and _PP_RAB and get_conv_math() == 'bf16x3' and u.is_cuda)
+    out = _AttentionTail.apply(u, skip, fc1_w, fc2_w, w7, wc, bc, _carry_commit(skip), emit)
+    pp, _state.last_out_pp = getattr(_state, 'last_out_pp', None), None
+    if pp is not None:
+        out._srhip_pp = (pp, out._version)
+    return out
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -677,3 +677,47 @@ def test_a_missing_stash_is_an_error_not_a_wrong_gradient():
     with pytest.raises(RuntimeError, match='gradients of the block input'):
         y.sum().backward()
     ops._state.carry.clear(); ops._state.carry_expect.clear()
+
+
+def test_group_tail_hands_its_output_over_as_planes_bit_identical():
+    """A ResGroup that feeds a ResGroup leaves its output also as padded planes (ops.attention_tail emit_pp -> srhip_conv2d_fwd_dual):
+    the next group's first RAB and its weight gradient read them instead of a pp_from_f32 pass.  The planes hold exactly the split
+    the pass would produce, so output and every gradient are bit-identical to the run without the hand-over -- and it happened."""
+    from sradsgan_amd import model as M, ops
+    if ops.get_conv_math() != 'bf16x3':
+        pytest.skip('padded planes are a split-bf16 format')
+    torch.manual_seed(5)
+    net = M.GeneratorResNet(M.ResGroup, n_residual_blocks=3, n_basic_blocks=2, upscale_factor=2).to(DEV)
+    x = torch.rand(2, 3, 24, 20, device=DEV)
+    dy = torch.randn(2, 3, 48, 40, device=DEV)
+    seen = []
+    orig = ops.rab_block
+
+    def spy(xx, *a, **k):
+        tag = getattr(xx, '_srhip_pp', None)
+        seen.append(tag is not None and tag[1] == xx._version)
+        return orig(xx, *a, **k)
+
+    def run(handover):
+        old, ops._X_PP = ops._X_PP, handover
+        try:
+            for p in net.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = net(xi)
+            y.backward(dy)
+            return y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+        finally:
+            ops._X_PP = old
+
+    import sradsgan_amd.model.sradsgan as MS
+    MS.ops.rab_block = spy
+    try:
+        y1, dx1, g1 = run(True)
+    finally:
+        MS.ops.rab_block = orig
+    assert seen == [False, True, True, True, True, True], seen      # every RAB but the trunk's first finds its input as planes
+    y0, dx0, g0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
