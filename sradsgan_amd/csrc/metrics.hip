@@ -44,7 +44,71 @@ __global__ __launch_bounds__(256) void quant_sse_kernel(const float* __restrict_
   }
 }
 
-// one thread per interior pixel (all channels); a = test image, b = ground truth, both [N,H,W,C] floats
+// Tiled form (round 5, C <= 4): a block walks 16 x 16 tiles of interior pixels; the 22 x 22 halo of both images is quantised ONCE into
+// LDS bytes, a thread sums its 7 x 7 window from there in int32 -- the byte sums are exact integers either way, so the five moments are
+// the same numbers the fp64 accumulation of the reference form below produces -- and only the SSIM formula itself runs in fp64.
+// (The reference form reads and quantises 294 floats from global memory per pixel: 140 us for sixteen 216 x 216 images, 2.4 % of the
+// inference step.)
+__global__ __launch_bounds__(256) void ssim_u8_tiled_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            double* __restrict__ partial, int h, int w, int c) {
+  constexpr int T = 16, HT = T + 6;
+  __shared__ unsigned char qa[HT * HT * 4], qb[HT * HT * 4];
+  __shared__ double red[256];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int ih = h - 6, iw = w - 6;
+  const int tiles_x = (iw + T - 1) / T, tiles_y = (ih + T - 1) / T;
+  const double c1 = (0.01 * 255.0) * (0.01 * 255.0), c2 = (0.03 * 255.0) * (0.03 * 255.0);
+  const double cov_norm = 49.0 / 48.0;
+  const int ly = tid >> 4, lx = tid & 15;
+  double acc = 0.0;
+  for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+    const int ty0 = (t / tiles_x) * T, tx0 = (t % tiles_x) * T;
+    __syncthreads();
+    for (int e = tid; e < HT * HT * c; e += 256) {
+      const int pix = e / c, ch = e - pix * c;
+      const int gy = ty0 + pix / HT, gx = tx0 + pix % HT;
+      int va = 0, vb = 0;
+      if (gy < h && gx < w) {
+        const size_t o = (((size_t)n * h + gy) * w + gx) * c + ch;
+        va = quant_u8(a[o]);
+        vb = quant_u8(b[o]);
+      }
+      qa[pix * 4 + ch] = (unsigned char)va;
+      qb[pix * 4 + ch] = (unsigned char)vb;
+    }
+    __syncthreads();
+    if (ty0 + ly < ih && tx0 + lx < iw) {
+      for (int ch = 0; ch < c; ++ch) {
+        int sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 7; ++dx) {
+            const int o = ((ly + dy) * HT + lx + dx) * 4 + ch;
+            const int va = qa[o], vb = qb[o];
+            sx += va;
+            sy += vb;
+            sxx += va * va;
+            syy += vb * vb;
+            sxy += va * vb;
+          }
+        const double ux = (double)sx / 49.0, uy = (double)sy / 49.0;
+        const double vx = cov_norm * ((double)sxx / 49.0 - ux * ux), vy = cov_norm * ((double)syy / 49.0 - uy * uy);
+        const double vxy = cov_norm * ((double)sxy / 49.0 - ux * uy);
+        acc += ((2.0 * ux * uy + c1) * (2.0 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+      }
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) partial[(size_t)n * gridDim.x + blockIdx.x] = red[0];
+}
+
+// reference form: one thread per interior pixel (all channels); a = test image, b = ground truth, both [N,H,W,C] floats
 __global__ __launch_bounds__(256) void ssim_u8_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       double* __restrict__ partial, int h, int w, int c) {
   __shared__ double red[256];
@@ -124,7 +188,10 @@ int srhip_quant_sse(const float* a, const float* b, unsigned long long* partial,
 /* partial: double [n][srhip_metric_blocks()] = sums of the per-pixel, per-channel SSIM index over the interior */
 int srhip_ssim_u8(const float* a, const float* b, double* partial, int n, int h, int w, int c, void* stream) {
   SRHIP_REQUIRE(a && b && partial && n > 0 && h >= 7 && w >= 7 && c > 0, "ssim_u8: bad argument (needs H, W >= 7)");
-  hipLaunchKernelGGL(ssim_u8_kernel, dim3(METRIC_BLOCKS, n), dim3(256), 0, as_stream(stream), a, b, partial, h, w, c);
+  if (c <= 4)
+    hipLaunchKernelGGL(ssim_u8_tiled_kernel, dim3(METRIC_BLOCKS, n), dim3(256), 0, as_stream(stream), a, b, partial, h, w, c);
+  else
+    hipLaunchKernelGGL(ssim_u8_kernel, dim3(METRIC_BLOCKS, n), dim3(256), 0, as_stream(stream), a, b, partial, h, w, c);
   return check_launch("ssim_u8");
 }
 
