@@ -37,6 +37,7 @@ class _State:
     carry = None                    # token -> [gradients stashed for a block input by its other consumers] (carry_open)
     carry_expect = None             # token -> number of consumers that committed to stash at forward time
     carry_token = 0
+    wgrad_seq = 0                   # weight-gradient requests so far (the age of a pending launch, _age_pending)
 
 
 _state = _State()
@@ -808,6 +809,7 @@ def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
     if gw is None or (want_b and b is not None and gb is None):
         return False
     side = _state.wgrad_stream
+    _age_pending()
     item = (x, dy, gw, gb, tuple(release))
     if side is None:
         _launch_wgrad_pp([item], None)
@@ -815,7 +817,7 @@ def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
     if _state.wgrad_group > 1:
         key = ('pp', tuple(x.shape), w.shape[0], gb is not None)
         q = _state.pending.setdefault(key, [])
-        q.append(item + (_stream().value,))
+        q.append(item + (_stream().value, _state.wgrad_seq))
         if len(q) >= 2:
             _flush_key(key)
         return True
@@ -860,6 +862,21 @@ def _flush_key(key):
         _hold_for_side(side, it[1])
 
 
+_WGRAD_MAX_AGE = int(os.environ.get('SRHIP_WGRAD_MAX_AGE', '8'))    # weight-gradient calls a launch may wait for a partner (0: until the next flush point)
+
+
+def _age_pending():
+    """Called at every weight-gradient request: a pending launch whose partner has not shown up within _WGRAD_MAX_AGE further requests
+    goes out alone.  The RAB pairs meet within 4-5 requests; shapes that occur ONCE per backward (the up-sampler's conv at 54^2 and at
+    108^2) used to wait for the flush at the END of the generator's backward and then ran, alone on the chip, for 0.5 ms after the
+    main stream had finished (`tools/step_tail.py`, profiles/r05_step_tail_before.txt)."""
+    _state.wgrad_seq += 1
+    if not _WGRAD_MAX_AGE or _WGRAD_DEFER or not _state.pending:
+        return
+    for key in [k for k, q in _state.pending.items() if q and _state.wgrad_seq - q[0][-1] > _WGRAD_MAX_AGE]:
+        _flush_key(key)
+
+
 def flush_pending_wgrads():
     """Launches every weight gradient that is still waiting for a partner of its shape.  Called wherever something is about to
     order itself behind "all weight gradients so far": the exchange, the joins of the step, the end of direct_param_grads()."""
@@ -880,6 +897,7 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
         if side is None:
             conv2d_wgrad_raw(x, dy, tuple(w.shape), stride, pad, want_b, xrowscale, xchanscale, out=(gw, gb))
             return None, None
+        _age_pending()
         # Weight gradients are off the critical path of backward (nothing reads them before the optimiser):
         # run them on a side stream so the partially filled last wave of each data-gradient kernel and of
         # each wgrad kernel overlap.  Same-parameter accumulations stay ordered (one side stream).
@@ -891,7 +909,7 @@ def wgrad_for_params(w, b, x, dy, stride, pad, want_b, xrowscale=None, xchanscal
             # launch them together -- one full wave of blocks serves both with half the split-K partials each
             key = (tuple(x.shape), cout, stride, pad, gb is not None)
             q = _state.pending.setdefault(key, [])
-            q.append((x, dy, gw, gb, stride, pad, _stream().value))     # + the stream that produced the operands
+            q.append((x, dy, gw, gb, stride, pad, _stream().value, _state.wgrad_seq))     # + the stream that produced the operands, + the request number
             if len(q) >= _state.wgrad_group and not _WGRAD_DEFER:
                 _flush_key(key)
             return None, None
