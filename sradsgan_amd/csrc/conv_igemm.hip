@@ -592,18 +592,24 @@ template <int ND>
 __global__ __launch_bounds__(576) void wgrad_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ partial, int N, int H, int W, int cin,
                                                             int ldx, int ldy, int tiles_h, int tiles_w) {
+  // Round 5: thread = (row group rg, filter row kh, ci) instead of (tap, ci): it reads the 18 staged x values of one halo row ONCE and
+  // uses them for the three kw taps (x[px + kw]), keeping 3 x ND sums; the three row groups split the 16 rows of a patch (6 / 5 / 5)
+  // and are summed through LDS at the end in a fixed order.  LDS traffic per patch: 864 row reads + 768 broadcasts per 64 lanes
+  // instead of 2304 + 2304 (the kernel was LDS-bound: 350 us for one pass over the 382 MB tensor).
   constexpr int PW = 16, PH = 16, PWP = PW + 2, NPX = (PH + 2) * PWP;   // 324 halo pixels
   constexpr int NLD = (NPX * 16 + 575) / 576;        // float4 loads per thread and patch (9)
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ float xs[];                      // [324][64], then the patch's 256 dy vectors (float4, zero outside the image)
   float4* dys = reinterpret_cast<float4*>(xs + NPX * 64);
   const int tid = threadIdx.x;
-  const int tap = tid >> 6, ci = tid & 63;
-  const int kh = tap / 3, kw = tap - kh * 3;
+  const int rg = tid / 192, kh = (tid - rg * 192) >> 6, ci = tid & 63;     // wave-uniform rg, kh
+  const int row0 = rg == 0 ? 0 : (rg == 1 ? 6 : 11), row1 = rg == 0 ? 6 : (rg == 1 ? 11 : 16);
   const int ci0 = blockIdx.y * 64;
   const int npatch = N * tiles_h * tiles_w;
   const int tpi = tiles_h * tiles_w;
-  f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+  f32x2 acc01[3], acc23[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc01[k] = acc23[k] = f32x2{0.f, 0.f};
   float4 stage[NLD];
   float4 dstage = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](int pid) {                         // the halo of patch pid and its dy vectors: global -> registers
@@ -633,7 +639,6 @@ __global__ __launch_bounds__(576) void wgrad_narrow_kernel(const float* __restri
   };
   int pid = blockIdx.x;
   if (pid < npatch) fetch(pid);
-  const float* xb = xs + (kh * PWP + kw) * 64 + ci;
   for (; pid < npatch; pid += gridDim.x) {
     __syncthreads();                                  // the previous patch is consumed
 #pragma unroll
@@ -644,30 +649,43 @@ __global__ __launch_bounds__(576) void wgrad_narrow_kernel(const float* __restri
     if (tid < PH * PW) dys[tid] = dstage;
     __syncthreads();
     if (pid + (int)gridDim.x < npatch) fetch(pid + gridDim.x);   // next patch's loads fly under this patch's arithmetic
-#pragma unroll 2
-    for (int py = 0; py < PH; ++py) {
-      float v[PW];
-      float4 d[PW];
+    for (int py = row0; py < row1; ++py) {
+      const float* xr = xs + ((py + kh) * PWP) * 64 + ci;        // halo row py + kh: x[py + kh - 1][-1 .. 16]
+      float xv[PWP];
+#pragma unroll
+      for (int j = 0; j < PWP; ++j) xv[j] = xr[j * 64];
 #pragma unroll
       for (int px = 0; px < PW; ++px) {
-        v[px] = xb[(py * PWP + px) * 64];
-        d[px] = dys[py * PW + px];                   // uniform address: one broadcast read
-      }
+        const float4 d = dys[py * PW + px];           // uniform address: one broadcast read
+        const f32x2 d01 = {d.x, d.y}, d23 = {d.z, d.w};
 #pragma unroll
-      for (int px = 0; px < PW; ++px) {
-        const f32x2 vv = {v[px], v[px]};
-        const f32x2 d01 = {d[px].x, d[px].y}, d23 = {d[px].z, d[px].w};
-        acc01 = __builtin_elementwise_fma(vv, d01, acc01);
-        if (ND > 2) acc23 = __builtin_elementwise_fma(vv, d23, acc23);
+        for (int kw = 0; kw < 3; ++kw) {
+          const f32x2 vv = {xv[px + kw], xv[px + kw]};
+          acc01[kw] = __builtin_elementwise_fma(vv, d01, acc01[kw]);
+          if (ND > 2) acc23[kw] = __builtin_elementwise_fma(vv, d23, acc23[kw]);
+        }
       }
     }
   }
+  // the three row groups' sums: red[rg][co][tap][ci] in the (consumed) halo area, then one thread per (co, tap, ci)
+  __syncthreads();
+  float* red = xs;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int tap = kh * 3 + kw;
+    red[((rg * 4 + 0) * 9 + tap) * 64 + ci] = acc01[kw].x;
+    if (ND > 1) red[((rg * 4 + 1) * 9 + tap) * 64 + ci] = acc01[kw].y;
+    if (ND > 2) red[((rg * 4 + 2) * 9 + tap) * 64 + ci] = acc23[kw].x;
+    if (ND > 3) red[((rg * 4 + 3) * 9 + tap) * 64 + ci] = acc23[kw].y;
+  }
+  __syncthreads();
   const int ktot = 9 * cin;
-  float* o = partial + (size_t)blockIdx.x * ND * ktot + tap * cin + ci0 + ci;
-  o[0] = acc01.x;
-  if (ND > 1) o[ktot] = acc01.y;
-  if (ND > 2) o[2 * ktot] = acc23.x;
-  if (ND > 3) o[3 * ktot] = acc23.y;
+  for (int e = tid; e < ND * 9 * 64; e += 576) {
+    const int c = e & 63, tap = (e >> 6) % 9, co = e / (9 * 64);
+    const int o = (co * 9 + tap) * 64 + c;
+    const float v = (red[o] + red[4 * 9 * 64 + o]) + red[2 * 4 * 9 * 64 + o];
+    partial[(size_t)blockIdx.x * ND * ktot + (size_t)co * ktot + tap * cin + ci0 + c] = v;
+  }
 }
 
 // partial[s][co][(kh,kw,ci)] --sum over s--> dw[co][ci][kh][kw]
@@ -778,6 +796,7 @@ static WgradPlan plan_wgrad(int M, int cout, int ktot) {
   long tiles = (long)cdiv(cout, p.bm) * cdiv(ktot, p.bn);
   int nchunks = cdiv(M, BK);
   long want = (1024 + tiles - 1) / tiles;          // ~4 blocks per CU overall
+  if (cout <= 4 && want < 256) want = 256;         // wgrad_narrow_kernel: one 576-thread block per CU, one partial tile per block
   long maxsplit = (nchunks + 15) / 16;             // at least 16 chunks (256 pixels) per split
   long ns = want < 1 ? 1 : want;
   if (ns > maxsplit) ns = maxsplit;
