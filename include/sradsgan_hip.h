@@ -420,6 +420,12 @@ int srhip_bn_train_bwd_acc(const float* dy, const float* x, const float* y, cons
                            const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                            float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
                            int apply_act, void* stream);
+/* ABI 9: the same WITHOUT y: the LeakyReLU mask is the sign of the pre-activation recomputed from x with the forward's own expression
+ * ((x - mean) * invstd * gamma + beta: bit-identical, so the same sign as y's) -- one tensor read less in each of the two passes */
+int srhip_bn_train_bwd_acc_x(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                             float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                             int apply_act, void* stream);
 /* eval()-mode nn.BatchNorm2d (+ activation): the per-channel affine of the running statistics (SRGAN's generator at
  * validation time, model/srgan.py; the SRADSGAN discriminator is never put in eval()).  Inference only.   */
 int srhip_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
@@ -434,6 +440,11 @@ int srhip_bn_train_bwd_bwd_acc(const float* ddx, const float* dy, const float* x
                                const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
                                float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
                                int apply_act, void* stream);   /* ABI 7: + acc_gamma[c] += g_gamma[c] unless NULL */
+/* ABI 9: the second-order pass without y (mask from the recomputed pre-activation, like srhip_bn_train_bwd_acc_x) */
+int srhip_bn_train_bwd_bwd_acc_x(const float* ddx, const float* dy, const float* x, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                                 float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                                 int apply_act, void* stream);
 
 /* ---- validation metrics (mfeNew_validate / validate, sradsgan.py:1314-1325; utils/utils.py:923-962):
  *      images quantised like ToPILImage (mul(255).byte(): truncate + wrap, no clamp), NHWC floats in.

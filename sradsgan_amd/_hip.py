@@ -114,7 +114,9 @@ SIGNATURES = {
     'srhip_attn_tail_eval_pooled': (_i, [_vp, _vp, _vp, _sz, _i] + [_vp] * 6 + [_i] * 5 + [_vp]),
     'srhip_sum_n': (_i, [_vp, _i, _vp, _l, _vp]),
     'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_train_bwd_acc_x': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_train_bwd_bwd_acc_x': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_metric_blocks': (_i, []),
     'srhip_quant_sse': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'srhip_ssim_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

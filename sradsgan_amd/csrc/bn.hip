@@ -16,7 +16,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict__ a, const float* __restrict__ x,
                                                         const float* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ partial,
-                                                        long rows, int c, long rows_per_block, float slope, int act) {
+                                                        long rows, int c, long rows_per_block, float slope, int act,
+                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
+  // beta != nullptr (MODE 1, round 5): the LeakyReLU mask is the sign of the RECOMPUTED pre-activation (x - mean) * invstd * gamma + beta
+  // -- the forward's own expression, contraction off in both kernels: the same bits, hence the same sign as y's -- instead of a read
+  // of y: 2 reads instead of 3 in this pass, 2 + 1 write instead of 3 + 1 in bn_bwd_apply_kernel (both run at the HBM roofline)
   __shared__ float4 red0[256], red1[256];
   const int tid = threadIdx.x;
   const int q = c / 4, nrl = 256 / q;
@@ -31,6 +35,11 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
     p0 = *reinterpret_cast<const float4*>(mean + cq * 4);
     p1 = *reinterpret_cast<const float4*>(invstd + cq * 4);
   }
+  float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;
+  if (MODE == 1 && beta != nullptr) {
+    pg = *reinterpret_cast<const float4*>(gamma + cq * 4);
+    pb = *reinterpret_cast<const float4*>(beta + cq * 4);
+  }
   if (rl < nrl)
     for (long r = r0 + rl; r < r1; r += nrl) {
       const size_t o = (size_t)r * c + cq * 4;
@@ -43,7 +52,15 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
         float4 g = *reinterpret_cast<const float4*>(a + o);
         const float4 v = *reinterpret_cast<const float4*>(x + o);
         if (act) {
-          const float4 yy = *reinterpret_cast<const float4*>(y + o);
+          float4 yy;
+          if (beta != nullptr) {
+            yy.x = (v.x - p0.x) * p1.x * pg.x + pb.x;
+            yy.y = (v.y - p0.y) * p1.y * pg.y + pb.y;
+            yy.z = (v.z - p0.z) * p1.z * pg.z + pb.z;
+            yy.w = (v.w - p0.w) * p1.w * pg.w + pb.w;
+          } else {
+            yy = *reinterpret_cast<const float4*>(y + o);
+          }
           g.x = yy.x > 0.f ? g.x : g.x * slope;
           g.y = yy.y > 0.f ? g.y : g.y * slope;
           g.z = yy.z > 0.f ? g.z : g.z * slope;
@@ -195,23 +212,33 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    float* __restrict__ dx, long n4, int c, float inv_n, float slope, int act) {
+                                    float* __restrict__ dx, long n4, int c, float inv_n, float slope, int act,
+                                    const float* __restrict__ beta = nullptr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
     const int ch = (int)((i * 4) % c);
     float4 g = reinterpret_cast<const float4*>(dy)[i];
     const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
     if (act) {
-      const float4 yy = reinterpret_cast<const float4*>(y)[i];
+      float4 yy;
+      if (beta != nullptr) {                           // the forward's pre-activation, recomputed (see bn_reduce_stage1)
+        const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+        yy.x = (v.x - mu.x) * is.x * ga.x + be.x;
+        yy.y = (v.y - mu.y) * is.y * ga.y + be.y;
+        yy.z = (v.z - mu.z) * is.z * ga.z + be.z;
+        yy.w = (v.w - mu.w) * is.w * ga.w + be.w;
+      } else {
+        yy = reinterpret_cast<const float4*>(y)[i];
+      }
       g.x = yy.x > 0.f ? g.x : g.x * slope;
       g.y = yy.y > 0.f ? g.y : g.y * slope;
       g.z = yy.z > 0.f ? g.z : g.z * slope;
       g.w = yy.w > 0.f ? g.w : g.w * slope;
     }
-    const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
-    const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
     const float4 dg = *reinterpret_cast<const float4*>(dgamma + ch);
     const float4 db = *reinterpret_cast<const float4*>(dbeta + ch);
     float4 o;
@@ -234,7 +261,8 @@ __global__ __launch_bounds__(256) void bn_bwd2_stage1(const float* __restrict__ 
                                                       const float* __restrict__ x, const float* __restrict__ y,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       float* __restrict__ partial, long rows, int c,
-                                                      long rows_per_block, float slope, int act) {
+                                                      long rows_per_block, float slope, int act,
+                                                      const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
   __shared__ float4 red[5][256];
   const int tid = threadIdx.x;
   const int q = c / 4, nrl = 256 / q;
@@ -243,6 +271,11 @@ __global__ __launch_bounds__(256) void bn_bwd2_stage1(const float* __restrict__ 
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4);
   const float4 is = *reinterpret_cast<const float4*>(invstd + cq * 4);
+  float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;
+  if (beta != nullptr) {                               // mask from the recomputed pre-activation (see bn_reduce_stage1)
+    pg = *reinterpret_cast<const float4*>(gamma + cq * 4);
+    pb = *reinterpret_cast<const float4*>(beta + cq * 4);
+  }
   float4 s[5];
   for (int k = 0; k < 5; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < nrl)
@@ -252,7 +285,15 @@ __global__ __launch_bounds__(256) void bn_bwd2_stage1(const float* __restrict__ 
       float4 g = *reinterpret_cast<const float4*>(dy + o);
       const float4 v = *reinterpret_cast<const float4*>(x + o);
       if (act) {
-        const float4 yy = *reinterpret_cast<const float4*>(y + o);
+        float4 yy;
+        if (beta != nullptr) {
+          yy.x = (v.x - mu.x) * is.x * pg.x + pb.x;
+          yy.y = (v.y - mu.y) * is.y * pg.y + pb.y;
+          yy.z = (v.z - mu.z) * is.z * pg.z + pb.z;
+          yy.w = (v.w - mu.w) * is.w * pg.w + pb.w;
+        } else {
+          yy = *reinterpret_cast<const float4*>(y + o);
+        }
         g.x = yy.x > 0.f ? g.x : g.x * slope;
         g.y = yy.y > 0.f ? g.y : g.y * slope;
         g.z = yy.z > 0.f ? g.z : g.z * slope;
@@ -314,7 +355,7 @@ __global__ void bn_bwd2_apply_kernel(const float* __restrict__ u, const float* _
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                      const float* __restrict__ gamma, const float* __restrict__ coef,
                                      float* __restrict__ g_dy, float* __restrict__ g_x, long n4, int c, float slope,
-                                     int act) {
+                                     int act, const float* __restrict__ beta = nullptr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
@@ -323,14 +364,23 @@ __global__ void bn_bwd2_apply_kernel(const float* __restrict__ u, const float* _
     const float4 g0 = reinterpret_cast<const float4*>(dy)[i];
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (act) {
-      const float4 yy = reinterpret_cast<const float4*>(y)[i];
-      mk = make_float4(yy.x > 0.f ? 1.f : slope, yy.y > 0.f ? 1.f : slope, yy.z > 0.f ? 1.f : slope,
-                       yy.w > 0.f ? 1.f : slope);
-    }
     const float4 mu = *reinterpret_cast<const float4*>(mean + ch);
     const float4 is = *reinterpret_cast<const float4*>(invstd + ch);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + ch);
+    if (act) {
+      float4 yy;
+      if (beta != nullptr) {
+        const float4 be = *reinterpret_cast<const float4*>(beta + ch);
+        yy.x = (v.x - mu.x) * is.x * ga.x + be.x;
+        yy.y = (v.y - mu.y) * is.y * ga.y + be.y;
+        yy.z = (v.z - mu.z) * is.z * ga.z + be.z;
+        yy.w = (v.w - mu.w) * is.w * ga.w + be.w;
+      } else {
+        yy = reinterpret_cast<const float4*>(y)[i];
+      }
+      mk = make_float4(yy.x > 0.f ? 1.f : slope, yy.y > 0.f ? 1.f : slope, yy.z > 0.f ? 1.f : slope,
+                       yy.w > 0.f ? 1.f : slope);
+    }
     const float4 ub = *reinterpret_cast<const float4*>(coef + ch);
     const float4 ww = *reinterpret_cast<const float4*>(coef + c + ch);
     const float4 pp = *reinterpret_cast<const float4*>(coef + 2 * c + ch);
@@ -408,11 +458,32 @@ int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const fl
                                 workspace_bytes, rows, c, slope, apply_act, stream);
 }
 
+static int bn_train_bwd_impl(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                             float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                             int apply_act, void* stream);
 int srhip_bn_train_bwd_acc(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                            const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                            float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
                            int apply_act, void* stream) {
-  SRHIP_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && (y || !apply_act),
+  return bn_train_bwd_impl(dy, x, y, gamma, nullptr, save_mean, save_invstd, dx, dgamma, dbeta, acc_gamma, acc_beta, workspace,
+                           workspace_bytes, rows, c, slope, apply_act, stream);
+}
+/* ABI 9: the same backward WITHOUT the activation output y: the LeakyReLU mask is the sign of the pre-activation recomputed from x
+ * (mean, invstd, gamma, beta: the forward's own expression, bit for bit) -- one tensor read less in each of the two passes */
+int srhip_bn_train_bwd_acc_x(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                             float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                             int apply_act, void* stream) {
+  SRHIP_REQUIRE(beta != nullptr, "bn_train_bwd_acc_x: beta is what replaces y");
+  return bn_train_bwd_impl(dy, x, nullptr, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, acc_gamma, acc_beta, workspace,
+                           workspace_bytes, rows, c, slope, apply_act, stream);
+}
+static int bn_train_bwd_impl(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                             float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                             int apply_act, void* stream) {
+  SRHIP_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && (y || beta || !apply_act),
                 "bn_train_bwd: null tensor");
   SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_bwd: C must be a multiple of 4, <= 1024");
   SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_bn_workspace(rows, c), "bn_train_bwd: workspace too small");
@@ -420,13 +491,13 @@ int srhip_bn_train_bwd_acc(const float* dy, const float* x, const float* y, cons
   const long nblk = bn_nblk(rows), rpb = (rows + nblk - 1) / nblk;
   float* part = static_cast<float*>(workspace);
   hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3((int)nblk), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, part, rows,
-                     c, rpb, slope, apply_act);
+                     c, rpb, slope, apply_act, gamma, beta);
   hipLaunchKernelGGL(bn_bwd_stage2, dim3(cdiv(c, 16)), dim3(16 * BN_SUBS), 0, st, part, dgamma, dbeta, (int)nblk, c, acc_gamma, acc_beta);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, gamma, dgamma,
-                     dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act);
+                     dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act, beta);
   return check_launch("bn_train_bwd");
 }
 
@@ -440,11 +511,31 @@ int srhip_bn_train_bwd_bwd(const float* ddx, const float* dy, const float* x, co
                                     workspace_bytes, rows, c, slope, apply_act, stream);
 }
 
+static int bn_bwd2_impl(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                        float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                        int apply_act, void* stream);
 int srhip_bn_train_bwd_bwd_acc(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma,
                                const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
                                float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
                                int apply_act, void* stream) {
-  SRHIP_REQUIRE(ddx && dy && x && gamma && save_mean && save_invstd && g_dy && g_x && g_gamma && (y || !apply_act),
+  return bn_bwd2_impl(ddx, dy, x, y, gamma, nullptr, save_mean, save_invstd, g_dy, g_x, g_gamma, acc_gamma, workspace, workspace_bytes,
+                      rows, c, slope, apply_act, stream);
+}
+/* ABI 9: the second-order pass without y (mask from the recomputed pre-activation, like srhip_bn_train_bwd_acc_x) */
+int srhip_bn_train_bwd_bwd_acc_x(const float* ddx, const float* dy, const float* x, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                                 float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                                 int apply_act, void* stream) {
+  SRHIP_REQUIRE(beta != nullptr, "bn_train_bwd_bwd_acc_x: beta is what replaces y");
+  return bn_bwd2_impl(ddx, dy, x, nullptr, gamma, beta, save_mean, save_invstd, g_dy, g_x, g_gamma, acc_gamma, workspace, workspace_bytes,
+                      rows, c, slope, apply_act, stream);
+}
+static int bn_bwd2_impl(const float* ddx, const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, float* g_dy, float* g_x, float* g_gamma,
+                        float* acc_gamma, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                        int apply_act, void* stream) {
+  SRHIP_REQUIRE(ddx && dy && x && gamma && save_mean && save_invstd && g_dy && g_x && g_gamma && (y || beta || !apply_act),
                 "bn_train_bwd_bwd: null tensor");
   SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_bwd_bwd: C must be a multiple of 4, <= 1024");
   SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_bn_bwd2_workspace(rows, c), "bn_train_bwd_bwd: workspace too small");
@@ -453,14 +544,14 @@ int srhip_bn_train_bwd_bwd_acc(const float* ddx, const float* dy, const float* x
   float* part = static_cast<float*>(workspace);
   float* coef = part + (size_t)nblk * 5 * c;
   hipLaunchKernelGGL(bn_bwd2_stage1, dim3((int)nblk), dim3(256), 0, st, ddx, dy, x, y, save_mean, save_invstd, part, rows,
-                     c, rpb, slope, apply_act);
+                     c, rpb, slope, apply_act, gamma, beta);
   hipLaunchKernelGGL(bn_bwd2_stage2, dim3(cdiv(c, 16)), dim3(16 * BN_SUBS), 0, st, part, save_invstd, coef, g_gamma, (int)nblk, c,
                      rows, acc_gamma);
   const long n4 = rows * c / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(bn_bwd2_apply_kernel, dim3(blocks), dim3(256), 0, st, ddx, dy, x, y, save_mean, save_invstd, gamma,
-                     coef, g_dy, g_x, n4, c, slope, apply_act);
+                     coef, g_dy, g_x, n4, c, slope, apply_act, beta);
   return check_launch("bn_train_bwd_bwd");
 }
 

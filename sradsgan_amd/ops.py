@@ -1834,9 +1834,12 @@ def _bn_reference_bwd(dy, x, y, gamma, eps, slope):
     return dx, dgamma, dbeta
 
 
+_BN_BWD_X = os.environ.get('SRHIP_BN_BWD_X', '1') == '1'      # A/B knob: 0 = the BatchNorm backward reads y for the LeakyReLU mask (rounds 1-4)
+
+
 class _BNTrainBwd(Function):
     @staticmethod
-    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope, acc_gamma=None, acc_beta=None):
+    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope, acc_gamma=None, acc_beta=None, beta=None):
         # acc_gamma / acc_beta: the parameters' gradient slots (direct_param_grads mode): the kernel adds into them itself
         # (srhip_bn_train_bwd_acc) instead of two add launches per BatchNorm backward
         # NB: save the tensors autograd handed us (not layout-converted copies), or the second-order
@@ -1848,19 +1851,25 @@ class _BNTrainBwd(Function):
         dx = torch.empty_like(xc, memory_format=CL)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(lib.srhip_bn_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
-        _hip.check(lib.srhip_bn_train_bwd_acc(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
-                                              _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws), ws.numel() * 4,
-                                              rows, c, float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
+        if beta is not None and slope is not None and _BN_BWD_X:
+            # the LeakyReLU mask from the recomputed pre-activation instead of a read of y (srhip_bn_train_bwd_acc_x): the same bits
+            _hip.check(lib.srhip_bn_train_bwd_acc_x(_p(dyc), _p(xc), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), _p(mean),
+                                                    _p(invstd), _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws),
+                                                    ws.numel() * 4, rows, c, float(slope), 1, _stream()), 'bn_train_bwd_x')
+        else:
+            _hip.check(lib.srhip_bn_train_bwd_acc(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
+                                                  _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws), ws.numel() * 4,
+                                                  rows, c, float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
         ctx.eps, ctx.slope = eps, slope
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(dy, x, y, gamma, mean, invstd)
+        ctx.save_for_backward(dy, x, y, gamma, mean, invstd, beta)
         return dx, dgamma, dbeta
 
     @staticmethod
     def backward(ctx, ddx, ddgamma, ddbeta):
-        dy, x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy, x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         if ddx is None and ddgamma is None and ddbeta is None:
-            return (None,) * 10
+            return (None,) * 11
         if ddx is not None and ddgamma is None and ddbeta is None and not torch.is_grad_enabled():
             # the gradient-penalty case: one fused second-order pass (3 launches instead of ~40 ATen ops)
             uc, dyc, xc, yc = nhwc(ddx), nhwc(dy), nhwc(x), nhwc(y)
@@ -1871,20 +1880,25 @@ class _BNTrainBwd(Function):
             g_gamma = torch.empty_like(gamma)
             ws = torch.empty(lib.srhip_bn_bwd2_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
             slot = None if _skip_param_grads(gamma) else _grad_slot(gamma)   # direct_param_grads(): straight into the arena, by the kernel
-            _hip.check(lib.srhip_bn_train_bwd_bwd_acc(_p(uc), _p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()),
-                                                      _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(slot), _p(ws),
-                                                      ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
-                                                      int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
+            if beta is not None and ctx.slope is not None and _BN_BWD_X:
+                _hip.check(lib.srhip_bn_train_bwd_bwd_acc_x(_p(uc), _p(dyc), _p(xc), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()),
+                                                            _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(slot), _p(ws),
+                                                            ws.numel() * 4, rows, c, float(ctx.slope), 1, _stream()), 'bn_train_bwd_bwd_x')
+            else:
+                _hip.check(lib.srhip_bn_train_bwd_bwd_acc(_p(uc), _p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()),
+                                                          _p(mean), _p(invstd), _p(g_dy), _p(g_x), _p(g_gamma), _p(slot), _p(ws),
+                                                          ws.numel() * 4, rows, c, float(ctx.slope or 0.0),
+                                                          int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
             if slot is not None:
                 g_gamma = None
-            return g_dy, g_x, None, g_gamma, None, None, None, None, None, None
+            return g_dy, g_x, None, g_gamma, None, None, None, None, None, None, None
         with torch.enable_grad():
             dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
             outs = _bn_reference_bwd(dy_, x_, y, g_, ctx.eps, ctx.slope)
             pairs = [(o, d) for o, d in zip(outs, (ddx, ddgamma, ddbeta)) if d is not None]
             gdy, gx, gg = torch.autograd.grad([o for o, _ in pairs], [dy_, x_, g_], [d for _, d in pairs],
                                               allow_unused=True)
-        return gdy, gx, None, gg, None, None, None, None, None, None
+        return gdy, gx, None, gg, None, None, None, None, None, None, None
 
 
 class _BNTrainFwd(Function):
@@ -1915,9 +1929,9 @@ class _BNTrainFwd(Function):
             # iteration (the main stream, D(gen_hr)), which would make the main stream wait for the D stream's backward
             gg, gb = _grad_slot(gamma), _grad_slot(beta)
             if gg is not None and gb is not None:
-                dx, _, _ = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, gg, gb)
+                dx, _, _ = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, gg, gb, beta)
                 return dx, None, None, None, None, None, None, None
-        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope)
+        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, None, None, beta)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

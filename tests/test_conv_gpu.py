@@ -678,3 +678,42 @@ def test_stride2_data_gradient_phases_in_one_launch_are_bit_identical(case, math
     assert torch.equal(got, want)
     ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt.detach().double(), dy.double(), stride=2, padding=1)
     assert (got.double() - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 64, 9, 7), (32, 128, 27, 27), (3, 512, 5, 5)])
+def test_batch_norm_backward_without_reading_y_is_bit_identical(shape):
+    """srhip_bn_train_bwd_acc_x (ABI 9): the LeakyReLU mask of the BatchNorm backward from the recomputed pre-activation
+    ((x - mean) * invstd * gamma + beta: the forward kernel's own expression) instead of a read of y -- the same sign bit for bit,
+    so dx / dgamma / dbeta are bit-identical to the y-reading form (sradsgan.py:478-479 and its autograd)."""
+    from sradsgan_amd import ops
+    dev = torch.device('cuda:0')
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + 11 * h)
+    x = (torch.randn(n, c, h, w, generator=g) * 0.7 + 0.3).to(dev)
+    dy = torch.randn(n, c, h, w, generator=g).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(c, generator=g)).to(dev), (0.1 * torch.randn(c, generator=g)).to(dev)
+
+    def run(from_x):
+        old, ops._BN_BWD_X = ops._BN_BWD_X, from_x
+        try:
+            bn = torch.nn.BatchNorm2d(c).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(gamma), bn.bias.copy_(beta)
+            xx = x.clone().requires_grad_()
+            y = ops.batch_norm_act(xx, bn, 0.2)
+            y.backward(dy)
+            first = (xx.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+            # and the gradient penalty's route: first order with a graph, then the fused second-order pass (srhip_bn_train_bwd_bwd_acc_x)
+            bn.weight.grad = bn.bias.grad = None
+            x2 = x.clone().requires_grad_()
+            y2 = ops.batch_norm_act(x2, bn, 0.2)
+            (gx,) = torch.autograd.grad(y2, x2, dy, create_graph=True)
+            ((gx.norm(2, 1) - 1) ** 2).mean().backward()
+            return first + (gx.detach().clone(), x2.grad.clone(), bn.weight.grad.clone())
+        finally:
+            ops._BN_BWD_X = old
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(('dx', 'dgamma', 'dbeta', 'dx (graph)', 'd penalty / dx', 'd penalty / dgamma'), a, b):
+        assert torch.equal(u, v), name
