@@ -230,6 +230,11 @@ int srhip_colsum(const float* dy, float* db, void* workspace, size_t workspace_b
 /* ---- elementwise / permutation pieces of the same call sites --------------------------------- */
 /* dx = dy * (y > 0 ? 1 : slope): backward of the in-place LeakyReLU (:242,:479) from its OUTPUT  */
 int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, float slope, void* stream);
+/* ABI 9: the same with the SIGN of y as a bit mask (one bit per element): y != NULL reads y and also WRITES the mask, y == NULL reads the
+ * mask INSTEAD of y.  The gradient penalty (sradsgan.py:621, 639) applies the backward of the discriminator's first LeakyReLU twice to
+ * the same 382 MB activation -- first order, then its double backward --: the second application reads 12 MB. */
+size_t srhip_lrelu_mask_bytes(long count);
+int srhip_lrelu_bwd_bits(const float* dy, const float* y, void* mask, float* dx, long count, float slope, void* stream);
 /* ABI 7: out = ((srcs[0] + srcs[1]) + srcs[2]) + ... (n = 2..16 dense tensors of `count` floats, count % 4 == 0, 16-byte aligned):
  * the stratified dense-sampling bus of GeneratorResNet.forward (sradsgan.py:455-460: `bus = bus + out` after every residual
  * group) in one pass, same summation order as the chained torch adds it replaces.                                            */

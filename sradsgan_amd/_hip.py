@@ -55,6 +55,8 @@ SIGNATURES = {
     'srhip_colsum_workspace': (_sz, [_l, _i]),
     'srhip_colsum': (_i, [_vp, _vp, _vp, _sz, _l, _i, _i, _vp]),
     'srhip_lrelu_bwd': (_i, [_vp, _vp, _vp, _l, _f, _vp]),
+    'srhip_lrelu_mask_bytes': (_sz, [_l]),
+    'srhip_lrelu_bwd_bits': (_i, [_vp, _vp, _vp, _vp, _l, _f, _vp]),
     'srhip_maxpool2x2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'srhip_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),

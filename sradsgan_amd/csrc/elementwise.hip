@@ -30,6 +30,38 @@ __global__ void lrelu_bwd_kernel(const float4* __restrict__ dy, const float4* __
     dx[i] = g;
   }
 }
+// The same with the SIGN of y as a bit mask (round 5): MODE 1 reads y and also WRITES one bit per element -- per wave chunk of 64 float4s
+// the four component ballots, 8 dwords --, MODE 2 reads that mask INSTEAD of y (32 bytes per 1024 bytes of y).  The gradient penalty
+// applies the backward of the discriminator's first LeakyReLU twice to the same 382 MB activation (first order, then its double
+// backward): the second application reads 12 MB.
+template <int MODE>
+__global__ __launch_bounds__(256) void lrelu_bwd_bits_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                             unsigned long long* __restrict__ bits, float4* __restrict__ dx, long n4, float slope) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;   // a multiple of 64: a wave always holds one aligned chunk of 64 float4s
+  const int lane = threadIdx.x & 63;
+  for (; (i & ~63L) < n4; i += stride) {               // whole waves iterate together (the ballots need every lane of the chunk)
+    const bool live = i < n4;
+    float4 g = live ? dy[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bool p0, p1, p2, p3;
+    unsigned long long* w = bits + (i >> 6) * 4;
+    if (MODE == 1) {
+      const float4 v = live ? y[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      p0 = v.x > 0.f; p1 = v.y > 0.f; p2 = v.z > 0.f; p3 = v.w > 0.f;
+      const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2), b3 = __ballot(p3);
+      if (lane == 0) { w[0] = b0; w[1] = b1; w[2] = b2; w[3] = b3; }
+    } else {
+      p0 = (w[0] >> lane) & 1ull; p1 = (w[1] >> lane) & 1ull; p2 = (w[2] >> lane) & 1ull; p3 = (w[3] >> lane) & 1ull;
+    }
+    if (live) {
+      g.x = p0 ? g.x : g.x * slope;
+      g.y = p1 ? g.y : g.y * slope;
+      g.z = p2 ? g.z : g.z * slope;
+      g.w = p3 ? g.w : g.w * slope;
+      dx[i] = g;
+    }
+  }
+}
 // out = ((src[0] + src[1]) + src[2]) + ... in that order: the generator's stratified dense-sampling bus (sradsgan.py:455-460) as ONE
 // pass over its n terms instead of n - 1 chained adds that each re-read the running sum (12 x 72 MB -> 14 x 24 MB at B = 32)
 struct SumSrcs {
@@ -368,6 +400,25 @@ int srhip_lrelu_bwd(const float* dy, const float* y, float* dx, long count, floa
     hipLaunchKernelGGL(lrelu_bwd_tail_kernel, dim3(cdiv(count - done, 256)), dim3(256), 0, st, dy, y, dx, done, count,
                        slope);
   return check_launch("lrelu_bwd");
+}
+
+/* ABI 9: dx = dy * LeakyReLU'(y) with the sign of y as a bit mask: y != NULL: read y and WRITE the mask; y == NULL: READ the mask instead of
+ * y.  count % 4 == 0, 16-byte aligned tensors; mask = srhip_lrelu_mask_bytes(count) bytes (one bit per element, chunks of 256 elements). */
+size_t srhip_lrelu_mask_bytes(long count) { return count <= 0 ? 0 : (size_t)((count / 4 + 63) / 64) * 32; }
+int srhip_lrelu_bwd_bits(const float* dy, const float* y, void* mask, float* dx, long count, float slope, void* stream) {
+  SRHIP_REQUIRE(dy && mask && dx && count >= 0 && count % 4 == 0, "lrelu_bwd_bits: bad argument (count % 4 == 0)");
+  SRHIP_REQUIRE(((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx) | ((uintptr_t)mask)) & 15) == 0, "lrelu_bwd_bits: 16-byte aligned tensors");
+  if (count == 0) return SRHIP_OK;
+  const long n4 = count / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (y != nullptr)
+    hipLaunchKernelGGL(lrelu_bwd_bits_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)dy, (const float4*)y,
+                       static_cast<unsigned long long*>(mask), (float4*)dx, n4, slope);
+  else
+    hipLaunchKernelGGL(lrelu_bwd_bits_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)dy, (const float4*)nullptr,
+                       static_cast<unsigned long long*>(mask), (float4*)dx, n4, slope);
+  return check_launch("lrelu_bwd_bits");
 }
 
 int srhip_sum_n(const float* const* srcs, int n, float* out, long count, void* stream) {

@@ -1018,19 +1018,44 @@ def lrelu_bwd_raw(dy, y, slope):
 # --------------------------------------------------------------------------------------------- #
 
 
+_LRELU_BITS = os.environ.get('SRHIP_LRELU_BITS', '1') == '1'    # A/B knob: 0 = every application of a LeakyReLU backward reads y
+
+
+def lrelu_bwd_bits_raw(dy, y, mask, slope):
+    """dx = dy * LeakyReLU'(y) through srhip_lrelu_bwd_bits: y given -> reads y and WRITES its sign bits into `mask`; y None -> reads
+    `mask` instead of y."""
+    _require_gpu(dy, 'lrelu_bwd_bits')
+    dy = nhwc(dy)
+    dx = torch.empty_like(dy, memory_format=CL)
+    _hip.check(_hip.lib().srhip_lrelu_bwd_bits(_p(dy), _p(nhwc(y)) if y is not None else None, _p(mask), _p(dx), dy.numel(), float(slope),
+                                               _stream()), 'lrelu_bwd_bits')
+    return dx
+
+
 class _LReluBwd(Function):
-    """g = dy * (y > 0 ? 1 : slope); linear in dy, the mask is a constant."""
+    """g = dy * (y > 0 ? 1 : slope); linear in dy, the mask is a constant.  Applied under a recorded graph (create_graph: the gradient
+    penalty's first-order pass) to a large activation it also leaves the SIGN BITS of y behind (1 / 32 of y's bytes), and its own
+    backward -- the same mask on another tensor -- reads those instead of y (`mask` travels as a non-differentiable tensor argument)."""
 
     @staticmethod
-    def forward(ctx, dy, y, slope):
+    def forward(ctx, dy, y, slope, mask=None):
         ctx.slope = slope
-        ctx.save_for_backward(y)
+        if mask is not None:                           # the double backward of an earlier application: y's sign bits instead of y
+            ctx.save_for_backward(y, mask)
+            return lrelu_bwd_bits_raw(dy, None, mask, slope)
+        if (_LRELU_BITS and ctx.needs_input_grad[0] and dy.is_cuda and dy.numel() % 4 == 0
+                and dy.numel() >= (1 << 22)):          # a graph is being recorded over this application: its backward will want the mask again
+            nbytes = _hip.lib().srhip_lrelu_mask_bytes(dy.numel())
+            mask = torch.empty((nbytes + 7) // 8, device=dy.device, dtype=torch.int64)
+            ctx.save_for_backward(y, mask)
+            return lrelu_bwd_bits_raw(dy, y, mask, slope)
+        ctx.save_for_backward(y, None)
         return lrelu_bwd_raw(dy, y, slope)
 
     @staticmethod
     def backward(ctx, gg):
-        (y,) = ctx.saved_tensors
-        return _LReluBwd.apply(gg, y, ctx.slope), None, None
+        y, mask = ctx.saved_tensors
+        return _LReluBwd.apply(gg, y, ctx.slope, mask), None, None, None
 
 
 class _ColSum(Function):

@@ -717,3 +717,35 @@ def test_batch_norm_backward_without_reading_y_is_bit_identical(shape):
     a, b = run(True), run(False)
     for name, u, v in zip(('dx', 'dgamma', 'dbeta', 'dx (graph)', 'd penalty / dx', 'd penalty / dgamma'), a, b):
         assert torch.equal(u, v), name
+
+
+@pytest.mark.gpu
+def test_lrelu_backward_with_sign_bits_is_bit_identical_first_and_second_order():
+    """srhip_lrelu_bwd_bits (ABI 9): the LeakyReLU backward that leaves y's sign bits behind and the one that reads them instead of y
+    -- what ops._LReluBwd does under a recorded graph (the gradient penalty) -- against the plain kernel: same bits, both orders,
+    sizes with a partial last wave chunk."""
+    from sradsgan_amd import ops, _hip
+    lib = _hip.lib()
+    for shape in ((8, 64, 96, 96), (3, 64, 37, 53), (1, 4, 5, 7)):
+        g = torch.Generator().manual_seed(sum(shape))
+        dy = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        gg = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        y = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        y[y.abs() < 0.15] = 0.0                                          # zeros take the slope, like the plain kernel
+        mask = torch.zeros((lib.srhip_lrelu_mask_bytes(dy.numel()) + 7) // 8, device='cuda', dtype=torch.int64)
+        assert torch.equal(ops.lrelu_bwd_bits_raw(dy, y, mask, 0.2), ops.lrelu_bwd_raw(dy, y, 0.2))
+        assert torch.equal(ops.lrelu_bwd_bits_raw(gg, None, mask, 0.2), ops.lrelu_bwd_raw(gg, y, 0.2))
+    # through autograd: first order under create_graph, then the double backward
+    dy = torch.randn(8, 64, 128, 128, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = torch.randn(8, 64, 128, 128, device='cuda').contiguous(memory_format=torch.channels_last)
+    outs = []
+    for bits in (True, False):
+        old, ops._LRELU_BITS = ops._LRELU_BITS, bits
+        try:
+            dy.grad = None
+            g1 = ops._LReluBwd.apply(dy, y, 0.2)
+            (g1 * g1).sum().backward()
+            outs.append((g1.detach().clone(), dy.grad.clone()))
+        finally:
+            ops._LRELU_BITS = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
