@@ -14,8 +14,11 @@ steps: a fresh box runs the first ~1 s of GPU work 20-30 % slower, which 3 warm-
 is still exactly K steps between two barrier + synchronize pairs.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, fp32 MFMA) timed with HIP
-                  events on the launch stream: algorithmic FLOPs per launch / average duration;
+  roofline     -- the dominant kernel (3x3 64->256 conv of the RAB stack, in the form the step launches it: padded-plane operands in
+                  the default split-bf16 arithmetic, cold operand sets in rotation) timed with HIP events on the launch stream:
+                  algorithmic FLOPs per launch / average duration, `traffic` = HBM bytes per launch from the committed PMC passes
+                  (refused when the kernel sources have changed since), `in_step_*` = the same launches timed inside extra steps;
+  roofline_wgrad -- the same for the weight-gradient launch the step runs (two convolutions per launch + reduce + its conversion share);
   exact_fp32_mode -- the same job re-timed over the same K steps with the conv contraction in exact fp32 (DESIGN.md section 3);
   cpu_baseline -- the CPU oracle (oracle/sradsgan_ref.py, a port of the reference step) timed on the
                   host cores of this box on a bounded sample (rank 0, N=1 only).
