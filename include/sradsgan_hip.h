@@ -245,6 +245,11 @@ int srhip_sum_n(const float* const* srcs, int n, float* out, long count, void* s
 int srhip_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
 int srhip_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int n, int h, int w, int c, int relu_input,
                          void* stream);
+/* ABI 9: the forward that also leaves a 2-byte record per 4 output elements (per channel: the arg-max position of the window, first
+ * maximum in scan order, and whether the maximum is > 0) -- n (h/2) (w/2) (c/4) records --, and the backward that reads the records
+ * INSTEAD of x (1 / 32 of its bytes): same dx as srhip_maxpool2x2_bwd. */
+int srhip_maxpool2x2_fwd_idx(const float* x, float* y, void* rec, int n, int h, int w, int c, void* stream);
+int srhip_maxpool2x2_bwd_idx(const float* dy, const void* rec, float* dx, int n, int h, int w, int c, int relu_input, void* stream);
 /* nn.PixelShuffle(r) (:382,:385) on NHWC, fused with the LeakyReLU(slope) that follows it (:383):
  * out[n,h*r+i,w*r+j,c] = act(in[n,h,w,c*r*r+i*r+j]);  backward = inverse permutation * mask(out) */
 int srhip_pixel_shuffle_fwd(const float* in, float* out, int n, int h, int w, int cout, int r,

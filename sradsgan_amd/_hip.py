@@ -59,6 +59,8 @@ SIGNATURES = {
     'srhip_lrelu_bwd_bits': (_i, [_vp, _vp, _vp, _vp, _l, _f, _vp]),
     'srhip_maxpool2x2_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'srhip_maxpool2x2_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'srhip_maxpool2x2_fwd_idx': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'srhip_maxpool2x2_bwd_idx': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'srhip_pixel_shuffle_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_pixel_shuffle_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'srhip_attn_tail_workspace': (_sz, [_i]),

@@ -235,6 +235,73 @@ __global__ void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __rest
   reinterpret_cast<float4*>(y)[idx] = o;
 }
 
+// The same forward that also leaves, per thread (4 channels of one output pixel), a 16-bit record of what the backward needs from
+// x: per channel the arg-max position of pool_bwd1 (2 bits: first maximum in window scan order) and whether that maximum is > 0
+// (1 bit) -- 1 / 32 of x's bytes.  maxpool2x2_bwd_idx_kernel reads the record instead of the four x values: the backward of VGG's
+// first pool reads 12 MB instead of the 382 MB activation (on the main stream, in the generator's backward).
+__global__ void maxpool2x2_fwd_idx_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned short* __restrict__ rec, int n, int h,
+                                          int w, int c) {
+  const int ho = h / 2, wo = w / 2, c4 = c / 4;
+  const long total = (long)n * ho * wo * c4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % c4);
+  long pix = idx / c4;
+  const int ow = (int)(pix % wo);
+  pix /= wo;
+  const int oh = (int)(pix % ho);
+  const int b = (int)(pix / ho);
+  const float* p = x + (((size_t)b * h + oh * 2) * w + ow * 2) * c + q * 4;
+  const float4 v00 = *reinterpret_cast<const float4*>(p), v01 = *reinterpret_cast<const float4*>(p + c);
+  const float4 v10 = *reinterpret_cast<const float4*>(p + (size_t)w * c), v11 = *reinterpret_cast<const float4*>(p + (size_t)w * c + c);
+  float4 o;
+  o.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x));
+  o.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+  o.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z));
+  o.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+  reinterpret_cast<float4*>(y)[idx] = o;
+  auto one = [](float a_, float b_, float c_, float d_) {      // pool_bwd1's comparisons
+    int am = 0;
+    float m = a_;
+    if (b_ > m) { m = b_; am = 1; }
+    if (c_ > m) { m = c_; am = 2; }
+    if (d_ > m) { m = d_; am = 3; }
+    return (unsigned)(am | ((m > 0.f) ? 4 : 0));
+  };
+  rec[idx] = (unsigned short)(one(v00.x, v01.x, v10.x, v11.x) | (one(v00.y, v01.y, v10.y, v11.y) << 3) | (one(v00.z, v01.z, v10.z, v11.z) << 6) |
+                              (one(v00.w, v01.w, v10.w, v11.w) << 9));
+}
+__global__ void maxpool2x2_bwd_idx_kernel(const float* __restrict__ dy, const unsigned short* __restrict__ rec, float* __restrict__ dx,
+                                          int n, int h, int w, int c, int relu) {
+  const int ho = h / 2, wo = w / 2, c4 = c / 4;
+  const long total = (long)n * ho * wo * c4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int q = (int)(idx % c4);
+  long pix = idx / c4;
+  const int ow = (int)(pix % wo);
+  pix /= wo;
+  const int oh = (int)(pix % ho);
+  const int b = (int)(pix / ho);
+  const size_t o00 = (((size_t)b * h + oh * 2) * w + ow * 2) * c + q * 4;
+  const size_t o01 = o00 + c, o10 = o00 + (size_t)w * c, o11 = o10 + c;
+  const float4 g = reinterpret_cast<const float4*>(dy)[idx];
+  const unsigned r = rec[idx];
+  const float gv[4] = {g.x, g.y, g.z, g.w};
+  float o[4][4];                                        // [window position][channel]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned f = (r >> (3 * k)) & 7u;
+    const float gg = (!relu || (f & 4u)) ? gv[k] : 0.f;
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) o[pos][k] = (f & 3u) == (unsigned)pos ? gg : 0.f;
+  }
+  *reinterpret_cast<float4*>(dx + o00) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+  *reinterpret_cast<float4*>(dx + o01) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+  *reinterpret_cast<float4*>(dx + o10) = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]);
+  *reinterpret_cast<float4*>(dx + o11) = make_float4(o[3][0], o[3][1], o[3][2], o[3][3]);
+}
+
 // backward of MaxPool2d(2,2) fused with the backward of the ReLU that produced its input x (= relu
 // output, so x >= 0): dx = dy at the first maximum of each window if that maximum is > 0, else 0.
 __device__ inline void pool_bwd1(float a, float b, float c, float d, float g, int relu, float& oa, float& ob,
@@ -504,6 +571,25 @@ int srhip_maxpool2x2_fwd(const float* x, float* y, int n, int h, int w, int c, v
   const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
   hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, y, n, h, w, c);
   return check_launch("maxpool2x2_fwd");
+}
+
+/* ABI 9: the pool forward that also leaves a 2-byte record per 4 output elements (arg-max position + "maximum > 0" per channel), and the
+ * backward that reads the record instead of x: n * (h/2) * (w/2) * (c/4) records */
+int srhip_maxpool2x2_fwd_idx(const float* x, float* y, void* rec, int n, int h, int w, int c, void* stream) {
+  SRHIP_REQUIRE(x && y && rec && n > 0 && h >= 2 && w >= 2 && c >= 4, "maxpool2x2_fwd_idx: bad argument");
+  SRHIP_REQUIRE(c % 4 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool2x2_fwd_idx: C % 4 == 0 and even H, W only");
+  const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2x2_fwd_idx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), x, y, static_cast<unsigned short*>(rec),
+                     n, h, w, c);
+  return check_launch("maxpool2x2_fwd_idx");
+}
+int srhip_maxpool2x2_bwd_idx(const float* dy, const void* rec, float* dx, int n, int h, int w, int c, int relu_input, void* stream) {
+  SRHIP_REQUIRE(dy && rec && dx && n > 0 && h >= 2 && w >= 2 && c >= 4, "maxpool2x2_bwd_idx: bad argument");
+  SRHIP_REQUIRE(c % 4 == 0 && h % 2 == 0 && w % 2 == 0, "maxpool2x2_bwd_idx: C % 4 == 0 and even H, W only");
+  const long total = (long)n * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(maxpool2x2_bwd_idx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), dy, static_cast<const unsigned short*>(rec),
+                     dx, n, h, w, c, relu_input);
+  return check_launch("maxpool2x2_bwd_idx");
 }
 
 int srhip_maxpool2x2_bwd(const float* dy, const float* x, float* dx, int n, int h, int w, int c, int relu_input,

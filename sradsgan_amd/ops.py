@@ -2024,6 +2024,29 @@ def max_pool2x2_raw(x):
     return y
 
 
+_POOL_IDX = os.environ.get('SRHIP_POOL_IDX', '1') == '1'        # A/B knob: 0 = the max-pool backward re-reads the pool's input
+
+
+def max_pool2x2_idx_raw(x):
+    """(y, rec): the pool and its 2-byte records per 4 outputs (arg-max position + "maximum > 0"), which max_pool2x2_bwd_idx_raw reads
+    instead of x."""
+    _require_gpu(x, 'max_pool2x2')
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h // 2, w // 2, x)
+    rec = torch.empty(n * (h // 2) * (w // 2) * (c // 4), device=x.device, dtype=torch.int16)
+    _hip.check(_hip.lib().srhip_maxpool2x2_fwd_idx(_p(x), _p(y), _p(rec), n, h, w, c, _stream()), 'maxpool2x2_fwd_idx')
+    return y, rec
+
+
+def max_pool2x2_bwd_idx_raw(dy, rec, x_shape, relu_input):
+    dy = nhwc(dy)
+    n, c, h, w = x_shape
+    dx = torch.empty(n, h, w, c, device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    _hip.check(_hip.lib().srhip_maxpool2x2_bwd_idx(_p(dy), _p(rec), _p(dx), n, h, w, c, int(relu_input), _stream()), 'maxpool2x2_bwd_idx')
+    return dx
+
+
 def max_pool2x2_bwd_raw(dy, x, relu_input):
     dy, x = nhwc(dy), nhwc(x)
     n, c, h, w = x.shape
@@ -2063,12 +2086,18 @@ class _VggFeatures(Function):
         x = nhwc(x)
         y1 = conv2d_fwd_raw(x, ws[0], bs[0], 1, 1, 0.0)
         y2 = conv2d_fwd_raw(y1, ws[1], bs[1], 1, 1, 0.0)
-        p1 = max_pool2x2_raw(y2)
+        idx = _POOL_IDX and ctx.needs_input_grad[0]      # a backward will follow: the pools leave 2-byte records instead of keeping y2 / y4
+        p1, r1 = max_pool2x2_idx_raw(y2) if idx else (max_pool2x2_raw(y2), None)
         y3 = conv2d_fwd_raw(p1, ws[2], bs[2], 1, 1, 0.0)
         y4 = conv2d_fwd_raw(y3, ws[3], bs[3], 1, 1, 0.0)
-        p2 = max_pool2x2_raw(y4)
+        p2, r2 = max_pool2x2_idx_raw(y4) if idx else (max_pool2x2_raw(y4), None)
         y5 = conv2d_fwd_raw(p2, ws[4], bs[4], 1, 1, 0.0)
-        ctx.save_for_backward(y1, y2, p1, y3, y4, p2, y5, *ws)
+        if idx:
+            ctx.shapes = (tuple(y2.shape), tuple(y4.shape))
+            ctx.save_for_backward(y1, r1, p1, y3, r2, p2, y5, *ws)
+        else:
+            ctx.shapes = None
+            ctx.save_for_backward(y1, y2, p1, y3, y4, p2, y5, *ws)
         ctx.x_shape = tuple(x.shape)
         return y5
 
@@ -2077,10 +2106,10 @@ class _VggFeatures(Function):
         y1, y2, p1, y3, y4, p2, y5, w1, w2, w3, w4, w5 = ctx.saved_tensors
         g = lrelu_bwd_raw(g, y5, 0.0)                                            # ReLU after conv3_1 (54x54, small)
         g = conv2d_dgrad_raw(g, w5, tuple(p2.shape), 1, 1)
-        g = max_pool2x2_bwd_raw(g, y4, True)                                      # pool2 + ReLU(conv2_2)
+        g = max_pool2x2_bwd_idx_raw(g, y4, ctx.shapes[1], True) if ctx.shapes else max_pool2x2_bwd_raw(g, y4, True)   # pool2 + ReLU(conv2_2) (y4 = its records)
         g = conv2d_dgrad_raw(g, w4, tuple(y3.shape), 1, 1, None, y3, 0.0)         # + ReLU(conv2_1)
         g = conv2d_dgrad_raw(g, w3, tuple(p1.shape), 1, 1)
-        g = max_pool2x2_bwd_raw(g, y2, True)                                      # pool1 + ReLU(conv1_2)
+        g = max_pool2x2_bwd_idx_raw(g, y2, ctx.shapes[0], True) if ctx.shapes else max_pool2x2_bwd_raw(g, y2, True)   # pool1 + ReLU(conv1_2) (y2 = its records)
         g = conv2d_dgrad_raw(g, w2, tuple(y1.shape), 1, 1, None, y1, 0.0)         # + ReLU(conv1_1)
         g = conv2d_dgrad_raw(g, w1, ctx.x_shape, 1, 1)
         return (g,) + (None,) * 10

@@ -749,3 +749,24 @@ def test_lrelu_backward_with_sign_bits_is_bit_identical_first_and_second_order()
         finally:
             ops._LRELU_BITS = old
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 64, 216, 216), (3, 128, 54, 38), (2, 8, 6, 10)])
+def test_max_pool_backward_from_argmax_records_is_bit_identical(shape):
+    """srhip_maxpool2x2_fwd_idx / _bwd_idx (ABI 9): the pool forward leaves a 2-byte record per 4 outputs (arg-max position and
+    "maximum > 0" per channel) and the backward reads it instead of the pool's input (VGG's two pools, sradsgan.py:92-95, in the
+    generator's backward): y and dx bit-identical to the x-reading pair, with ties, zeros and negative windows in the data."""
+    from sradsgan_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.relu(torch.randn(*shape, generator=g)).cuda().contiguous(memory_format=torch.channels_last)     # ReLU output: zeros, ties at 0
+    x[:, :, ::3, ::5] = 0.25                                                                                      # ties at a positive value
+    dy = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    y0 = ops.max_pool2x2_raw(x)
+    y1, rec = ops.max_pool2x2_idx_raw(x)
+    assert torch.equal(y0, y1)
+    for relu in (True, False):
+        assert torch.equal(ops.max_pool2x2_bwd_idx_raw(dy, rec, tuple(x.shape), relu), ops.max_pool2x2_bwd_raw(dy, x, relu))
+    xs = x - 0.3                                                                                                  # windows whose maximum is negative
+    _, rec = ops.max_pool2x2_idx_raw(xs)
+    assert torch.equal(ops.max_pool2x2_bwd_idx_raw(dy, rec, tuple(x.shape), True), ops.max_pool2x2_bwd_raw(dy, xs, True))
