@@ -204,6 +204,16 @@ int srhip_conv2d_dgrad_res3(const float* dy, const float* packed, float* dx, con
                             void* stream);
 int srhip_conv2d_dgrad_pp_res3(const void* dy, int dy_pp, const float* packed, float* dx, const float* residual, const float* residual2,
                                const float* residual3, int n, int h, int w, int cin, int cout, void* stream);
+/* The LeakyReLU mask between a plane-writing forward and the masked data gradient behind it as sign words: 1 bit per element, in the
+ * order the persistent patch kernel's lanes convert them (opaque; srhip_conv2d_pp_sign_bytes(n, h, w, channels) bytes, 0 = shape not
+ * served), written by _fwd_pp_signs (bias + LeakyReLU onto planes) and read by _dgrad_pp_signs INSTEAD of the hi plane of the
+ * producer's output (autograd of the RAB's conv1 -> LeakyReLU -> conv2, sradsgan.py:222-223: the data gradient reads 3 MB of mask
+ * instead of 48 at B = 32).  channels % 128 == 0; both calls must name the same [n, h, w, channels] tensor geometry. */
+size_t srhip_conv2d_pp_sign_bytes(int n, int h, int w, int channels);
+int srhip_conv2d_fwd_pp_signs(const void* x, int x_pp, const float* packed, const float* bias, void* y_planes, void* signs, size_t sign_bytes,
+                              int n, int h, int w, int cin, int cout, float slope, void* stream);
+int srhip_conv2d_dgrad_pp_signs(const void* dy, int dy_pp, const float* packed, void* dx_planes, const void* signs, size_t sign_bytes, float slope,
+                                int n, int h, int w, int cin, int cout, void* stream);
 long srhip_pp_plane_pixels(int n, int h, int w);
 int srhip_pp_from_f32(const float* x_nhwc, void* pp, int n, int h, int w, int c, int ldx, void* stream);
 int srhip_pp_to_f32(const void* pp, float* x_nhwc, int n, int h, int w, int c, int ldx, void* stream);

@@ -46,6 +46,9 @@ SIGNATURES = {
     'srhip_conv2d_dgrad_pp': (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _f] + [_i] * 5 + [_vp]),
     'srhip_conv2d_dgrad_res3': (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     'srhip_conv2d_dgrad_pp_res3': (_i, [_vp, _i] + [_vp] * 5 + [_i] * 5 + [_vp]),
+    'srhip_conv2d_pp_sign_bytes': (_sz, [_i] * 4),
+    'srhip_conv2d_fwd_pp_signs': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz] + [_i] * 5 + [_f, _vp]),
+    'srhip_conv2d_dgrad_pp_signs': (_i, [_vp, _i, _vp, _vp, _vp, _sz, _f] + [_i] * 5 + [_vp]),
     'srhip_conv2d_wgrad_pp_ok': (_i, [_i] * 5),
     'srhip_conv2d_wgrad_pp_workspace': (_sz, [_i] * 8),
     'srhip_conv2d_wgrad_pp': (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz] + [_i] * 6 + [_vp]),

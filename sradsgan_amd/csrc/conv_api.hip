@@ -579,6 +579,40 @@ int srhip_conv2d_dgrad_pp(const void* dy, int dy_pp, const float* packed, void* 
   if (pr) probe_end(pi, stream);
   return rc;
 }
+/* The LeakyReLU mask between a plane-writing forward and the masked data gradient behind it as SIGN WORDS (conv_patch_pers.hip, SIGNS):
+ * 1 bit per element in the order the persistent patch kernel's lanes convert them, instead of the consumer re-reading the hi plane of
+ * the producer's output (RAB: conv1's LeakyReLU, sradsgan.py:222-223 -- conv2's data gradient reads 3 MB instead of 48 at the bench
+ * shape).  The buffer is opaque: only a _dgrad_pp_signs call of the same [n, h, w, channels] geometry may read what _fwd_pp_signs wrote. */
+size_t srhip_conv2d_pp_sign_bytes(int n, int h, int w, int cout) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || g_conv_math != 1) return 0;
+  return (size_t)pp_sign_tiles(n, h, w, cout) * 2048;
+}
+int srhip_conv2d_fwd_pp_signs(const void* x, int x_pp, const float* packed, const float* bias, void* y_planes, void* signs, size_t sign_bytes,
+                              int n, int h, int w, int cin, int cout, float slope, void* stream) {
+  SRHIP_REQUIRE(signs && bias && (((uintptr_t)signs) & 15) == 0, "conv2d_fwd_pp_signs: bias and a 16-byte aligned sign buffer");
+  const size_t need = srhip_conv2d_pp_sign_bytes(n, h, w, cout);
+  SRHIP_REQUIRE(need > 0 && sign_bytes >= need, "conv2d_fwd_pp_signs: shape not served / sign buffer smaller than srhip_conv2d_pp_sign_bytes");
+  g_sign_req.words = signs; g_sign_req.bytes = sign_bytes; g_sign_req.mode = 1; g_sign_req.served = 0;
+  const int rc = srhip_conv2d_fwd_pp(x, x_pp, packed, bias, y_planes, 1, nullptr, 0, nullptr, n, h, w, cin, cout, slope, SRHIP_EPI_BIAS | SRHIP_EPI_LRELU, stream);
+  const bool served = g_sign_req.served != 0;
+  g_sign_req = SignRequest();
+  if (rc != SRHIP_OK) return rc;
+  SRHIP_REQUIRE(served, "conv2d_fwd_pp_signs: the launch that ran does not write sign words");
+  return SRHIP_OK;
+}
+int srhip_conv2d_dgrad_pp_signs(const void* dy, int dy_pp, const float* packed, void* dx_planes, const void* signs, size_t sign_bytes, float slope,
+                                int n, int h, int w, int cin, int cout, void* stream) {
+  SRHIP_REQUIRE(signs && (((uintptr_t)signs) & 15) == 0, "conv2d_dgrad_pp_signs: a 16-byte aligned sign buffer");
+  const size_t need = srhip_conv2d_pp_sign_bytes(n, h, w, cin);
+  SRHIP_REQUIRE(need > 0 && sign_bytes >= need, "conv2d_dgrad_pp_signs: shape not served / sign buffer smaller than srhip_conv2d_pp_sign_bytes");
+  g_sign_req.words = const_cast<void*>(signs); g_sign_req.bytes = sign_bytes; g_sign_req.mode = 2; g_sign_req.served = 0;
+  const int rc = srhip_conv2d_dgrad_pp(dy, dy_pp, packed, dx_planes, 1, nullptr, signs, slope, n, h, w, cin, cout, stream);
+  const bool served = g_sign_req.served != 0;
+  g_sign_req = SignRequest();
+  if (rc != SRHIP_OK) return rc;
+  SRHIP_REQUIRE(served, "conv2d_dgrad_pp_signs: the launch that ran does not read sign words");
+  return SRHIP_OK;
+}
 size_t srhip_conv2d_wgrad_pp_workspace(int nprob, int x_pp, int dy_pp, int n, int h, int w, int cin, int cout) {
   if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
   return flat_wgrad_workspace(nprob, x_pp, dy_pp, n, h, w, cin, cout);

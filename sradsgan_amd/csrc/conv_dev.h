@@ -6,6 +6,7 @@
 namespace srhip {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int FBK = 16;            // K values per chunk
 constexpr int FLS = FBK + 4;       // LDS row stride in floats (80 B: b128 reads hit all 64 banks once)
 constexpr unsigned F_OOB = 0x80000000u;
@@ -41,6 +42,14 @@ struct ResRequest {                 // rides beside ONE data-gradient call (conv
   int served = 0;
 };
 extern thread_local ResRequest g_res_req;
+struct SignRequest {                // rides beside ONE srhip_conv2d_fwd_pp / _dgrad_pp call (conv_api.hip: the _signs entries): the LeakyReLU
+  void* words = nullptr;            // mask as sign words of the persistent patch kernel's tiles (conv_patch_pers.hip, SIGNS)
+  size_t bytes = 0;
+  int mode = 0;                     // 1: the forward writes them, 2: the masked data gradient reads them
+  int served = 0;
+};
+extern thread_local SignRequest g_sign_req;
+long pp_sign_tiles(int n, int h, int w, int cout);   // tiles of the 128-wide persistent walk over [n, h, w, cout] (0: not served); 2048 bytes of sign words each
 // The stride^2 phases of a strided data gradient as ONE launch of fast_conv_dma_kernel (round 5): block ranges [first[k], first[k+1])
 // run phase k with its own virtual output grid and tap list.  Four quarter-filled launches of the discriminator's 14^2 / 27^2 layers
 // become one that fills the chip.  n = 0: a plain launch.

@@ -2598,6 +2598,18 @@ static bool plan_patch(const FastGeom& g, PatchGeom* pg, double min_eff = 0.70) 
   return true;
 }
 
+// Tiles of the persistent patch kernel's 128-wide walk over a stride-1 3x3 conv with an [n, h, w, cout] destination (the tile
+// decomposition depends on nothing else): the size of a sign-word buffer (SignRequest), 2048 bytes per tile.
+long pp_sign_tiles(int n, int h, int w, int cout) {
+  if (cout < 128 || cout % 128 != 0) return 0;
+  FastGeom g;
+  g.TH = 3; g.TW = 3; g.ss = 1; g.dsd = 1; g.ph = 0; g.pw = 0; g.dhs = 1; g.dws = 1; g.dh0 = -1; g.dw0 = -1;
+  g.Hd = g.OH = h; g.Wd = g.OW = w;
+  PatchGeom pg;
+  if (!plan_patch(g, &pg, 0.0)) return 0;
+  return (long)n * pg.tiles_h * pg.tiles_w * (cout / 128);
+}
+
 static int run_fast(const float* src, const float* wt, const float* bias, const float* residual,
                     const float* rowscale, const float* chanscale, const float* actmask, float* dst, const FastGeom& g,
                     hipStream_t st) {

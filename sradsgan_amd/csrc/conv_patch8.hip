@@ -425,7 +425,7 @@ static int num_cu8() {
 int launch_patch8(const float* src, const float* wt, const float* bias, const float* actmask, float* dst, const FastGeom& g_,
                   const PatchGeom& pg, int nbm, int eflags, hipStream_t st) {
   FastGeom g = g_;
-  if (!g_patch8 || g.src_pp || g.K < 256 || g.K % 8 != 0 || g.C % 16 != 0 || g.K > 1024) return -1;
+  if (!g_patch8 || g_sign_req.mode != 0 || g.src_pp || g.K < 256 || g.K % 8 != 0 || g.C % 16 != 0 || g.K > 1024) return -1;
   if (eflags & ~(SRHIP_EPI_BIAS | SRHIP_EPI_LRELU | SRHIP_EPI_ACTMASK)) return -1;
   if ((eflags & SRHIP_EPI_ACTMASK) && !actmask) return -1;
   const size_t total = (size_t)(g.w_bytes >> 2);

@@ -45,7 +45,12 @@ extern int g_fast_ablate;
 // its LDS round trip are skipped; a pp destination takes the epilogue's fp32 rows as 8-channel hi | lo stores (the same bytes as the
 // fp32 row), and its activation mask (the dgrad of a conv whose producer's LeakyReLU output is kept as planes) is read from the
 // mask tensor's hi plane at the same offsets.
-template <int BN, int EPI, int PROD = 0, int ABL = 0, int POOL = 0, int SRCPP = 0, int DSTPP = 0>
+// SIGNS (round 5, BN = 128 with a pp destination): the LeakyReLU mask as SIGN WORDS instead -- one 64-bit word per (tile, wave, lane):
+// the signs of the 8 items x 8 channels that lane converts in the epilogue (bit (p * NRP + i) * 8 + j).  1 = the bias + LeakyReLU
+// forward WRITES them (one more counted store per tile; `actmask` is the word buffer), 2 = the masked data gradient READS them (one
+// 8-byte load per lane and tile instead of eight 16-byte loads of the producer's hi plane: 3 MB instead of 48 at the bench shape).
+// Producer and consumer must walk the same tiles: same image size, same channel count, both BN = 128 (srhip_conv2d_pp_sign_bytes).
+template <int BN, int EPI, int PROD = 0, int ABL = 0, int POOL = 0, int SRCPP = 0, int DSTPP = 0, int SIGNS = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void conv_patch_pers_kernel(
     const float* __restrict__ src, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ actmask, float* __restrict__ dst, FastGeom g,
@@ -53,6 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   static_assert(POOL == 0 || (BN == 64 && PROD == 0 && ABL == 0), "pooling epilogue: 64-wide tile, split-bf16");
   static_assert((SRCPP == 0 && DSTPP == 0) || (PROD == 0 && ABL == 0), "padded planes: split-bf16 only");
   static_assert(DSTPP == 0 || POOL == 0, "a pp destination has no pooling epilogue");
+  static_assert(SIGNS == 0 || (BN == 128 && DSTPP == 1 && EPI == (SIGNS == 1 ? 3 : 32)), "sign words: 128-wide tile onto planes, bias + LeakyReLU forward / masked data gradient");
   constexpr bool TILED = PROD == 0;                 // B tiles from the tiled section of the packed weight (conv_internal.h)
   constexpr int XB = (ABL & 128) ? 2 : 1, XA = (ABL & 256) ? 2 : 1;   // ablations 128 / 256: every B / A DMA issued twice (marginal cost of the streams)
   constexpr bool DIRECT = (ABL & 64) != 0;          // ablation 64: epilogue straight from the accumulators with the MFMA operand roles swapped (see the header)
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   constexpr int LDS_B = 2 * PATCH_B + 3 * BSTAGE_B;
   constexpr int QPRW = WTN / 4;                     // float4s per staged row
   constexpr int NRD = 16 * QPRW / 64;               // float4s per lane per 16-row pass
-  constexpr int NS = 4 * NRD + (POOL ? 3 : 0);      // epilogue stores per wave per tile (always issued); POOL: + sum, max, arg partials
+  constexpr int NS = 4 * NRD + (POOL ? 3 : 0) + (SIGNS == 1 ? 1 : 0);   // epilogue stores per wave per tile (always issued); POOL: + sum, max, arg partials; SIGNS 1: + the sign word
   constexpr int STG_B = 16 * WTN * 4;               // staging bytes per wave
   static_assert(3 * STG_B <= PATCH_B && STG_B <= BSTAGE_B, "epilogue staging must fit the released buffers");
   __shared__ __attribute__((aligned(1024))) char lds[LDS_B];
@@ -119,15 +125,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, g.w_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, dst_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(POOL ? pool_out : dst, 0, POOL ? 3u * pool_sec : 0u, 0x00020000);   // pooling partials (POOL)
+  __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(SIGNS ? const_cast<float*>(actmask) : dst, 0, SIGNS ? (unsigned)ntiles * 2048u : 0u, 0x00020000);   // sign words (SIGNS)
 
   // ---- per-tile addressing ----
   struct TileAt {
-    int img, oh0, ow0, n0;
+    int img, oh0, ow0, n0, id;
   };
   auto decode = [&](int v) {
     const int tile = xcd_tile(v, ntiles);
     const int tile_n = tile % nblk_n, pid = tile / nblk_n;
     TileAt t;
+    t.id = tile;
     t.n0 = tile_n * BN;
     t.img = pid / tpi;
     const int prem = pid - t.img * tpi;
@@ -596,7 +604,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     };
     u32x4 am[2][NRP];                                   // mask = the hi halves of the producer's activation output (same geometry)
     unsigned moff[NRP];
-    if (flags & SRHIP_EPI_ACTMASK) {
+    const unsigned soff = (unsigned)((t.id * NW + wave) * 64 + ln) * 8u;     // SIGNS: this lane's word of this tile
+    unsigned long long sw = 0ull;
+    if (SIGNS == 2) {
+      const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_s, soff, 0, 0));
+      sw = (unsigned long long)w2.x | ((unsigned long long)w2.y << 32);
+    }
+    if (SIGNS != 2 && (flags & SRHIP_EPI_ACTMASK)) {
       mask_offsets(0, moff);
 #pragma unroll
       for (int i = 0; i < NRP; ++i) am[0][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + moff[i]);
@@ -608,7 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
       for (int u = 0; u < TN; ++u)
 #pragma unroll
         for (int r8 = 0; r8 < 8; ++r8) wl[((r8 & 3) + 8 * (r8 >> 2) + 4 * khe) * WTN + u * 32 + l31e] = acc[tt][u][rb + r8];
-      if (p < 3 && (flags & SRHIP_EPI_ACTMASK)) {       // (before this pass's stores are issued: see the fp32 form)
+      if (SIGNS != 2 && p < 3 && (flags & SRHIP_EPI_ACTMASK)) {       // (before this pass's stores are issued: see the fp32 form)
         mask_offsets(p + 1, moff);
 #pragma unroll
         for (int i = 0; i < NRP; ++i) am[nx][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(actmask) + moff[i]);
@@ -628,7 +642,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * g.slope;
         }
-        if (flags & SRHIP_EPI_ACTMASK) {
+        if (SIGNS == 1) {
+          unsigned byte = 0u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) byte |= (v[j] > 0.f ? 1u : 0u) << j;
+          sw |= (unsigned long long)byte << (8 * (p * NRP + i));
+        }
+        if (SIGNS == 2) {
+          const unsigned byte = (unsigned)(sw >> (8 * (p * NRP + i))) & 0xffu;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ((byte >> j) & 1u) ? v[j] : v[j] * g.slope;
+        } else if (flags & SRHIP_EPI_ACTMASK) {
           const unsigned mv[4] = {am[cur][i].x, am[cur][i].y, am[cur][i].z, am[cur][i].w};
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -651,6 +675,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         __builtin_amdgcn_raw_buffer_store_b128(piece, rs_d, ok ? tile_base2 + rel : F_OOB + 16u * (unsigned)(p * NRD + i), 0, 2);
       }
       if (p < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (SIGNS == 1) {                                   // 512 contiguous bytes per wave
+      const u32x2 w2 = {(unsigned)sw, (unsigned)(sw >> 32)};
+      __builtin_amdgcn_raw_buffer_store_b64(w2, rs_s, soff, 0, 0);
     }
     zero_acc();
   };
@@ -695,6 +723,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 }
 
 thread_local PoolRequest g_pool_req;
+thread_local SignRequest g_sign_req;
 int g_pers_small = 1;   // srhip_debug_set(11, v): 0 = launches with fewer tiles than block slots keep the one-tile kernels
 int g_pers_grid = 0;      // srhip_debug_set(5, n)
 int g_pers_abl = 0;       // srhip_debug_set(6, bits): timing-only ablations of conv_patch_pers_kernel<128, bias+lrelu>
@@ -745,6 +774,23 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
                        residual, actmask, dst, g, pg, nbm, nbn, pdbu, ndst16, PO_, PS_);                                         \
     return check_launch("conv_patch_pers_pp");                                                                                   \
   } while (0)
+    if (g_sign_req.mode != 0) {                       // sign words of the LeakyReLU mask: the two 128-wide plane-writing forms of the RAB or nothing
+      const int want = g_sign_req.mode == 1 ? (SRHIP_EPI_BIAS | SRHIP_EPI_LRELU) : SRHIP_EPI_ACTMASK;
+      if (!wide || !g.dst_pp || g.K % 128 != 0 || eflags != want || g_sign_req.bytes < (size_t)ntiles * 2048) return -1;
+      const float* words = static_cast<const float*>(g_sign_req.words);
+      g_sign_req.served = 1;
+#define SRHIP_PPS(EPI_, SRC_, SG_)                                                                                              \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((conv_patch_pers_kernel<128, EPI_, 0, 0, 0, SRC_, 1, SG_>), dim3(pgrid), dim3(256), 0, st, src, wsplit, bias, \
+                       residual, words, dst, g, pg, nbm, nbn, pdbu, ndst16, nullptr, 0u);                                      \
+    return check_launch("conv_patch_pers_pp_signs");                                                                           \
+  } while (0)
+      if (g_sign_req.mode == 1 && g.src_pp) SRHIP_PPS(3, 1, 1);
+      if (g_sign_req.mode == 1) SRHIP_PPS(3, 0, 1);
+      if (g.src_pp) SRHIP_PPS(32, 1, 2);
+      SRHIP_PPS(32, 0, 2);
+#undef SRHIP_PPS
+    }
     if (g.src_pp && !g.dst_pp && !wide) {
       if (g_pool_req.out != nullptr && nbn == 1 && g.K == 64 && (eflags == 0 || eflags == SRHIP_EPI_BIAS) &&
           2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW && ntiles <= 2 * (slots / 3)) {

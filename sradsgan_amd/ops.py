@@ -614,9 +614,17 @@ def conv2d_pp_ok(n, cin, h, w, cout):
     return bool(_hip.lib().srhip_conv2d_pp_ok(n, h, w, cin, cout))
 
 
-def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
+def pp_sign_words(n, h, w, channels, device):
+    """An (uninitialised) sign-word buffer for the LeakyReLU mask of an [n, channels, h, w] plane tensor (srhip_conv2d_pp_sign_bytes:
+    1 bit per element, in the persistent patch kernel's own order), or None when the shape is not served."""
+    nb = _hip.lib().srhip_conv2d_pp_sign_bytes(n, h, w, channels)
+    return torch.empty(nb // 8, device=device, dtype=torch.int64) if nb else None
+
+
+def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False, signs=None):
     """3x3 stride-1 pad-1 forward with padded-plane operands: x a PP or fp32 NHWC; out_pp = PP buffer to fill (then the result is that
-    PP) or None (fp32 result).  pool=True (fp32 result of 64 channels): also the CLAM pooling partials, as conv2d_fwd_pool_raw."""
+    PP) or None (fp32 result).  pool=True (fp32 result of 64 channels): also the CLAM pooling partials, as conv2d_fwd_pool_raw.
+    signs (pp_sign_words; bias + LeakyReLU onto planes): the launch also leaves the activation's sign words there."""
     cout, cin = w.shape[0], w.shape[1]
     n, _, h, wd = x.shape
     xpp = isinstance(x, PP)
@@ -624,6 +632,11 @@ def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
         _require_gpu(x, 'conv2d_fwd_pp')
         x = nhwc(x)
     dev = x.buf.device if xpp else x.device
+    if signs is not None:
+        _hip.check(_hip.lib().srhip_conv2d_fwd_pp_signs(ctypes.c_void_p(x.data_ptr()), int(xpp), _p(packed_weight(w, 0)), _p(bias.detach().contiguous()),
+                                                        ctypes.c_void_p(out_pp.data_ptr()), _p(signs), signs.numel() * 8, n, h, wd, cin, cout,
+                                                        float(slope), _stream()), 'conv2d_fwd_pp_signs')
+        return out_pp
     y = out_pp if out_pp is not None else torch.empty(n, h, wd, cout, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
     flags = 0
     b = None
@@ -643,9 +656,10 @@ def conv2d_fwd_pp_raw(x, w, bias, slope=None, out_pp=None, pool=False):
     return (y, (pl, sec, nseg.value)) if pool else y
 
 
-def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=None, extra=()):
+def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=None, extra=(), signs=None):
     """3x3 stride-1 pad-1 data gradient with padded-plane operands: dy a PP or fp32 NHWC; out_pp = PP buffer to fill, with
-    actmask = the PP of the LeakyReLU output that fed the forward conv; or fp32 result (+ residual)."""
+    actmask = the PP of the LeakyReLU output that fed the forward conv, or signs = the sign words its producer left
+    (conv2d_fwd_pp_raw(signs=)); or fp32 result (+ residual)."""
     cout, cin = w.shape[0], w.shape[1]
     n, _, h, wd = dy.shape
     ypp = isinstance(dy, PP)
@@ -653,6 +667,10 @@ def conv2d_dgrad_pp_raw(dy, w, residual=None, actmask=None, slope=0.0, out_pp=No
         _require_gpu(dy, 'conv2d_dgrad_pp')
         dy = nhwc(dy)
     dev = dy.buf.device if ypp else dy.device
+    if signs is not None:
+        _hip.check(_hip.lib().srhip_conv2d_dgrad_pp_signs(ctypes.c_void_p(dy.data_ptr()), int(ypp), _p(packed_weight(w, 1)), ctypes.c_void_p(out_pp.data_ptr()),
+                                                          _p(signs), signs.numel() * 8, float(slope), n, h, wd, cin, cout, _stream()), 'conv2d_dgrad_pp_signs')
+        return out_pp
     dx = out_pp if out_pp is not None else torch.empty(n, h, wd, cin, device=dev, dtype=torch.float32).permute(0, 3, 1, 2)
     if residual is not None:
         residual = nhwc(residual)
@@ -741,6 +759,7 @@ if os.environ.get('SRHIP_FLAT_BLOCKS'):                        # experiment: blo
 _X_PP = os.environ.get('SRHIP_X_PP', '1') == '1'                # A/B knob: 0 = a RAB's input never arrives as planes (conversion pass for its weight gradient)
 _DU_PP = os.environ.get('SRHIP_DU_PP', '1') == '1'              # A/B knob: 0 = conv2's gradients read the fp32 du (split in the dgrad kernel, pp_from_f32 pass for the weight gradient)
 _PP_RAB = os.environ.get('SRHIP_PP_RAB', '1') == '1'          # A/B knob: 0 = the RAB keeps t / dt as fp32 tensors (rounds 1-4)
+_PP_SIGNS = os.environ.get('SRHIP_PP_SIGNS', '1') == '1'      # A/B knob: 0 = conv2's data gradient reads its LeakyReLU mask from t's hi plane (48 MB) instead of sign words (3 MB)
 
 
 def rab_planes_ok(x, w1, w2):
@@ -1380,7 +1399,7 @@ class _RabBlock(Function):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
         ctx.carry = carry              # token under which the input's other consumers stash their gradients (carry_open)
-        ctx.t_pp = ctx.x_pp = None
+        ctx.t_pp = ctx.x_pp = ctx.signs = None
         _state.last_out_pp = None
         if rab_planes_ok(x, w1, w2):
             # round 5: t stays in padded split-bf16 planes between the block's own kernels (conv1's epilogue writes them, conv2 reads
@@ -1388,7 +1407,9 @@ class _RabBlock(Function):
             # input ALSO as planes, left by the previous block's tail (emit_pp): conv1 and its weight gradient read them
             n, _, h, wd = x.shape
             t_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
-            conv2d_fwd_pp_raw(x_pp if x_pp is not None else x, w1, b1, 0.2, out_pp=t_pp)
+            # conv1's epilogue also leaves the signs of t (1 bit per element): the mask conv2's data gradient applies
+            ctx.signs = pp_sign_words(n, h, wd, w1.shape[0], x.device) if (_PP_SIGNS and b1 is not None and any(ctx.needs_input_grad)) else None
+            conv2d_fwd_pp_raw(x_pp if x_pp is not None else x, w1, b1, 0.2, out_pp=t_pp, signs=ctx.signs)
             if pool_epilogue_ok(x, w2):
                 u, pool = conv2d_fwd_pp_raw(t_pp, w2, b2, pool=True)
             else:
@@ -1443,7 +1464,8 @@ class _RabBlock(Function):
         du_pp = plane_pool.get(n, u.shape[1], h, wd, x.device) if (_TAIL_FUSED and _DU_PP) else None
         du, dfc1, dfc2, dw7, dwc, dbc = _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, ctx.has_b[2], skip, du_pp)
         dt_pp = plane_pool.get(n, w1.shape[0], h, wd, x.device)
-        conv2d_dgrad_pp_raw(du_pp if du_pp is not None else du, w2, actmask=t_pp, slope=0.2, out_pp=dt_pp)   # * LeakyReLU'(t), planes out
+        signs, ctx.signs = ctx.signs, None
+        conv2d_dgrad_pp_raw(du_pp if du_pp is not None else du, w2, actmask=t_pp if signs is None else None, slope=0.2, out_pp=dt_pp, signs=signs)   # * LeakyReLU'(t), planes out
         dw2 = db2 = dw1 = db1 = None
         main = torch.cuda.current_stream()
         t_done = dt_done = False

@@ -61,6 +61,22 @@ def test_rab_convs_on_padded_planes_match_the_fp32_operand_kernels(case):
                 assert torch.equal(dt_pp.buf, ops.pp_from_f32(dt).buf)
                 dx_pp = ops.conv2d_dgrad_pp_raw(dt_pp, w1, residual=gres)
                 assert torch.equal(dx_pp, dx)
+                # the LeakyReLU mask as sign words (srhip_conv2d_fwd_pp_signs / _dgrad_pp_signs): the forward leaves 1 bit per element, the
+                # masked data gradient reads those instead of t's hi plane -- same planes out, from fp32 and from plane sources
+                x_pl, du_pl = ops.pp_from_f32(x), ops.pp_from_f32(du)
+                words = []
+                for xs, dus in ((x, du), (x_pl, du_pl)):
+                    signs = ops.pp_sign_words(n, h, w, 256, DEV)
+                    assert signs is not None and signs.numel() * 8 == lib.srhip_conv2d_pp_sign_bytes(n, h, w, 256)
+                    signs.fill_(0x5555555555555555)
+                    t_s = ops.conv2d_fwd_pp_raw(xs, w1, b1, 0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV), signs=signs)
+                    assert torch.equal(t_s.buf, t_ref.buf)
+                    dt_s = ops.conv2d_dgrad_pp_raw(dus, w2, slope=0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV), signs=signs)
+                    assert torch.equal(dt_s.buf, dt_pp.buf)
+                    words.append(signs)
+                assert torch.equal(words[0], words[1])
+                with pytest.raises(RuntimeError):                              # a buffer smaller than the walk's tiles need
+                    ops.conv2d_fwd_pp_raw(x, w1, b1, 0.2, out_pp=ops.pp_empty(n, 256, h, w, DEV), signs=words[0][:-2])
             finally:
                 lib.srhip_debug_set(5, 0)
                 lib.srhip_debug_set(0, 0)
