@@ -446,6 +446,13 @@ int srhip_bn_train_bwd_acc_x(const float* dy, const float* x, const float* gamma
                              const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                              float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
                              int apply_act, void* stream);
+/* ... and with dx = (that backward) + addend formed in the apply pass (addend may be dx): a BatchNorm input's second gradient -- the one
+ * the gradient penalty's double backward sends through the first-order backward's node, sradsgan.py:621-639 -- without autograd's
+ * separate accumulation pass. */
+int srhip_bn_train_bwd_acc_xa(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_invstd, const float* addend, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                              float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                              int apply_act, void* stream);
 /* eval()-mode nn.BatchNorm2d (+ activation): the per-channel affine of the running statistics (SRGAN's generator at
  * validation time, model/srgan.py; the SRADSGAN discriminator is never put in eval()).  Inference only.   */
 int srhip_bn_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,

@@ -122,6 +122,7 @@ SIGNATURES = {
     'srhip_sum_n': (_i, [_vp, _i, _vp, _l, _vp]),
     'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_acc_x': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
+    'srhip_bn_train_bwd_acc_xa': (_i, [_vp] * 13 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_bwd_acc_x': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_metric_blocks': (_i, []),

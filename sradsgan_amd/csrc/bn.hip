@@ -213,7 +213,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                     float* __restrict__ dx, long n4, int c, float inv_n, float slope, int act,
-                                    const float* __restrict__ beta = nullptr) {
+                                    const float* __restrict__ beta = nullptr, const float* addend = nullptr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
@@ -246,6 +246,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     o.y = ga.y * is.y * (g.y - db.y * inv_n - (v.y - mu.y) * is.y * (dg.y * inv_n));
     o.z = ga.z * is.z * (g.z - db.z * inv_n - (v.z - mu.z) * is.z * (dg.z * inv_n));
     o.w = ga.w * is.w * (g.w - db.w * inv_n - (v.w - mu.w) * is.w * (dg.w * inv_n));
+    if (addend != nullptr) {                           // (srhip_bn_train_bwd_acc_xa: x's other gradient, may be dx itself)
+      const float4 e = reinterpret_cast<const float4*>(addend)[i];
+      o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+    }
     reinterpret_cast<float4*>(dx)[i] = o;
   }
 }
@@ -461,7 +465,7 @@ int srhip_bn_train_bwd(const float* dy, const float* x, const float* y, const fl
 static int bn_train_bwd_impl(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* save_mean,
                              const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                              float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
-                             int apply_act, void* stream);
+                             int apply_act, void* stream, const float* addend = nullptr);
 int srhip_bn_train_bwd_acc(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
                            const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                            float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
@@ -479,10 +483,21 @@ int srhip_bn_train_bwd_acc_x(const float* dy, const float* x, const float* gamma
   return bn_train_bwd_impl(dy, x, nullptr, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, acc_gamma, acc_beta, workspace,
                            workspace_bytes, rows, c, slope, apply_act, stream);
 }
+/* The same with dx = (BatchNorm backward) + addend in the apply pass: where x has a second consumer whose gradient is already known (the
+ * gradient penalty's double backward reaches a BatchNorm input through the first-order backward's node AND through the forward node,
+ * sradsgan.py:621-639), the sum autograd would form with one more pass over three tensors.  addend may be dx (in place). */
+int srhip_bn_train_bwd_acc_xa(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                              const float* save_invstd, const float* addend, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
+                              float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
+                              int apply_act, void* stream) {
+  SRHIP_REQUIRE(beta != nullptr && addend != nullptr, "bn_train_bwd_acc_xa: beta and the addend");
+  return bn_train_bwd_impl(dy, x, nullptr, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, acc_gamma, acc_beta, workspace,
+                           workspace_bytes, rows, c, slope, apply_act, stream, addend);
+}
 static int bn_train_bwd_impl(const float* dy, const float* x, const float* y, const float* gamma, const float* beta, const float* save_mean,
                              const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* acc_gamma,
                              float* acc_beta, void* workspace, size_t workspace_bytes, long rows, int c, float slope,
-                             int apply_act, void* stream) {
+                             int apply_act, void* stream, const float* addend) {
   SRHIP_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && (y || beta || !apply_act),
                 "bn_train_bwd: null tensor");
   SRHIP_REQUIRE(rows > 0 && c >= 4 && c % 4 == 0 && c <= 1024, "bn_train_bwd: C must be a multiple of 4, <= 1024");
@@ -497,7 +512,7 @@ static int bn_train_bwd_impl(const float* dy, const float* x, const float* y, co
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dy, x, y, save_mean, save_invstd, gamma, dgamma,
-                     dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act, beta);
+                     dbeta, dx, n4, c, 1.f / (float)rows, slope, apply_act, beta, addend);
   return check_launch("bn_train_bwd");
 }
 

@@ -1882,11 +1882,35 @@ def _bn_reference_bwd(dy, x, y, gamma, eps, slope):
 
 
 _BN_BWD_X = os.environ.get('SRHIP_BN_BWD_X', '1') == '1'      # A/B knob: 0 = the BatchNorm backward reads y for the LeakyReLU mask (rounds 1-4)
+_BN_FOLD = os.environ.get('SRHIP_BN_FOLD', '1') == '1'        # A/B knob: 0 = autograd sums a BatchNorm input's two gradients in the penalty's double backward
+
+
+@contextlib.contextmanager
+def bn_fold_second_order():
+    """Around ONE backward through a gradient penalty's double-backward graph (sradsgan.py:621-639, 886): a BatchNorm input x receives two
+    gradients there -- from the first-order backward's node (d penalty / d x through the batch statistics and the normalised value) and,
+    later, from the forward node.  Inside this context the first is held back (not handed to autograd) and the forward node's backward
+    adds it in its apply pass (srhip_bn_train_bwd_acc_xa, in place): one pass over three tensors less per BatchNorm layer.  The second-
+    order nodes of a layer run before its forward node (their results feed it through the layers behind); a held-back gradient that
+    no forward node has taken when the backward ends is an error, not a silent loss."""
+    if not _BN_FOLD:
+        yield
+        return
+    prev, _state.bn_fold = getattr(_state, 'bn_fold', None), {}
+    ok = False
+    try:
+        yield
+        ok = True
+    finally:
+        left, _state.bn_fold = _state.bn_fold, prev
+        if ok and left:
+            raise RuntimeError('bn_fold_second_order: %d BatchNorm input gradient(s) of the double backward were never taken by a forward node' % len(left))
 
 
 class _BNTrainBwd(Function):
     @staticmethod
-    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope, acc_gamma=None, acc_beta=None, beta=None):
+    def forward(ctx, dy, x, y, gamma, mean, invstd, eps, slope, acc_gamma=None, acc_beta=None, beta=None, addend=None):
+        # addend (bn_fold_second_order): x's other gradient, added in the apply pass, in place (dx IS that buffer afterwards)
         # acc_gamma / acc_beta: the parameters' gradient slots (direct_param_grads mode): the kernel adds into them itself
         # (srhip_bn_train_bwd_acc) instead of two add launches per BatchNorm backward
         # NB: save the tensors autograd handed us (not layout-converted copies), or the second-order
@@ -1895,10 +1919,15 @@ class _BNTrainBwd(Function):
         n, c, h, w = x.shape
         rows = n * h * w
         lib = _hip.lib()
-        dx = torch.empty_like(xc, memory_format=CL)
+        fold = addend is not None and beta is not None and slope is not None and _BN_BWD_X and addend.is_contiguous(memory_format=CL)
+        dx = addend if fold else torch.empty_like(xc, memory_format=CL)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(lib.srhip_bn_workspace(rows, c) // 4, device=x.device, dtype=torch.float32)
-        if beta is not None and slope is not None and _BN_BWD_X:
+        if fold:
+            _hip.check(lib.srhip_bn_train_bwd_acc_xa(_p(dyc), _p(xc), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), _p(mean),
+                                                     _p(invstd), _p(addend), _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws),
+                                                     ws.numel() * 4, rows, c, float(slope), 1, _stream()), 'bn_train_bwd_xa')
+        elif beta is not None and slope is not None and _BN_BWD_X:
             # the LeakyReLU mask from the recomputed pre-activation instead of a read of y (srhip_bn_train_bwd_acc_x): the same bits
             _hip.check(lib.srhip_bn_train_bwd_acc_x(_p(dyc), _p(xc), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), _p(mean),
                                                     _p(invstd), _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws),
@@ -1907,6 +1936,8 @@ class _BNTrainBwd(Function):
             _hip.check(lib.srhip_bn_train_bwd_acc(_p(dyc), _p(xc), _p(yc), _p(gamma.detach().contiguous()), _p(mean), _p(invstd),
                                                   _p(dx), _p(dgamma), _p(dbeta), _p(acc_gamma), _p(acc_beta), _p(ws), ws.numel() * 4,
                                                   rows, c, float(slope or 0.0), int(slope is not None), _stream()), 'bn_train_bwd')
+        if addend is not None and not fold:
+            dx.add_(addend)
         ctx.eps, ctx.slope = eps, slope
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(dy, x, y, gamma, mean, invstd, beta)
@@ -1916,7 +1947,7 @@ class _BNTrainBwd(Function):
     def backward(ctx, ddx, ddgamma, ddbeta):
         dy, x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         if ddx is None and ddgamma is None and ddbeta is None:
-            return (None,) * 11
+            return (None,) * 12
         if ddx is not None and ddgamma is None and ddbeta is None and not torch.is_grad_enabled():
             # the gradient-penalty case: one fused second-order pass (3 launches instead of ~40 ATen ops)
             uc, dyc, xc, yc = nhwc(ddx), nhwc(dy), nhwc(x), nhwc(y)
@@ -1938,14 +1969,18 @@ class _BNTrainBwd(Function):
                                                           int(ctx.slope is not None), _stream()), 'bn_train_bwd_bwd')
             if slot is not None:
                 g_gamma = None
-            return g_dy, g_x, None, g_gamma, None, None, None, None, None, None, None
+            fold = getattr(_state, 'bn_fold', None)
+            if fold is not None and ctx.needs_input_grad[1] and (x.data_ptr(), tuple(x.shape)) not in fold:
+                fold[(x.data_ptr(), tuple(x.shape))] = g_x     # (bn_fold_second_order) the forward node of this layer adds it to its own
+                g_x = None
+            return g_dy, g_x, None, g_gamma, None, None, None, None, None, None, None, None
         with torch.enable_grad():
             dy_, x_, g_ = (t.detach().requires_grad_(True) for t in (dy, x, gamma))
             outs = _bn_reference_bwd(dy_, x_, y, g_, ctx.eps, ctx.slope)
             pairs = [(o, d) for o, d in zip(outs, (ddx, ddgamma, ddbeta)) if d is not None]
             gdy, gx, gg = torch.autograd.grad([o for o, _ in pairs], [dy_, x_, g_], [d for _, d in pairs],
                                               allow_unused=True)
-        return gdy, gx, None, gg, None, None, None, None, None, None, None
+        return gdy, gx, None, gg, None, None, None, None, None, None, None, None
 
 
 class _BNTrainFwd(Function):
@@ -1970,15 +2005,17 @@ class _BNTrainFwd(Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mean, invstd, beta = ctx.saved_tensors
+        fold = getattr(_state, 'bn_fold', None)
+        held = fold.pop((x.data_ptr(), tuple(x.shape)), None) if (fold and not torch.is_grad_enabled()) else None
         if not torch.is_grad_enabled() and not _skip_param_grads(gamma, beta):
             # direct_param_grads(): add into the arena slots here, on the stream this node runs on, instead of handing the
             # gradients to autograd -- its AccumulateGrad nodes run on the stream the parameter was FIRST used on in this
             # iteration (the main stream, D(gen_hr)), which would make the main stream wait for the D stream's backward
             gg, gb = _grad_slot(gamma), _grad_slot(beta)
             if gg is not None and gb is not None:
-                dx, _, _ = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, gg, gb, beta)
+                dx, _, _ = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, gg, gb, beta, held)
                 return dx, None, None, None, None, None, None, None
-        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, None, None, beta)
+        dx, dgamma, dbeta = _BNTrainBwd.apply(dy, x, y, gamma, mean, invstd, ctx.eps, ctx.slope, None, None, beta, held)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

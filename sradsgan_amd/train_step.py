@@ -178,7 +178,8 @@ class TrainStep:
         term the nodes of one thread are ordered by creation, and the penalty's two contributions to a weight (through
         the first-order backward's node, then through the forward node) are ordered by data dependence."""
         for t in terms:
-            torch.autograd.backward(t, inputs=inputs)
+            with ops.bn_fold_second_order():        # (the penalty term: a BatchNorm input's two gradients are summed by the BatchNorm backward itself)
+                torch.autograd.backward(t, inputs=inputs)
 
     def _exchange_start(self, which):
         """Hands a finished gradient arena to the exchange (dp.GradSync.start): called right after the backward that

@@ -256,6 +256,37 @@ def test_gradient_penalty_double_backward(golden):
         _close(O.digest(hp[k].grad), g['grad__' + k.replace('.', '__')], 5e-3, msg=k)
 
 
+def test_gradient_penalty_backward_with_folded_batch_norm_sums_is_bit_identical():
+    """ops.bn_fold_second_order (TrainStep._backward_terms): in the penalty's double backward (sradsgan.py:621-639, 886) a BatchNorm
+    input's gradient from the first-order backward's node is held back and added by the forward node's own backward pass
+    (srhip_bn_train_bwd_acc_xa) instead of by autograd: the same sums (a + b == b + a), so every discriminator gradient is bit-identical;
+    a held-back gradient nobody takes is an error."""
+    from sradsgan_amd import model as M, ops
+    from sradsgan_amd.train_step import TrainStep
+    torch.manual_seed(11)
+    hd = M.Discriminator().to(DEV)
+    step = TrainStep(torch.nn.Linear(1, 1).to(DEV), hd, torch.nn.Linear(1, 1).to(DEV))
+    real, fake = torch.rand(3, 3, 48, 40, device=DEV), torch.rand(3, 3, 48, 40, device=DEV)
+    alpha = torch.rand(3, 1, 1, 1, device=DEV)
+    grads = []
+    for fold in (True, False):
+        for p in hd.parameters():
+            p.grad = None
+        gp = step.gradient_penalty(real, fake, alpha)
+        if fold:
+            assert ops._BN_FOLD
+            with ops.bn_fold_second_order():
+                gp.backward()
+        else:
+            gp.backward()
+        grads.append([None if p.grad is None else p.grad.clone() for p in hd.parameters()])   # (the last conv's bias has no path to the penalty)
+    assert sum(a is not None for a in grads[0]) >= 20
+    assert all((a is None and b is None) or torch.equal(a, b) for a, b in zip(*grads))
+    with pytest.raises(RuntimeError):
+        with ops.bn_fold_second_order():
+            ops._state.bn_fold[(1, (1,))] = torch.zeros(1)
+
+
 def test_train_two_iterations_small(golden):
     worst, wdiff = train_parity(DEV, 'train_small', 2, 1, 2, 8, 4, 2, golden('train_small'))
     assert worst < TOL and wdiff < 5e-3, (worst, wdiff)
