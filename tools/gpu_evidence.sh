@@ -5,6 +5,12 @@ R=$GRAFT_REPO_ROOT
 E=$R/gpurun_out/evidence
 mkdir -p $E
 cd $R
+# the roofline passes first: the bench lines below read the traffic figures of THIS binary (bench.py refuses a file of another source hash)
+bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -12 $E/roofline2.log
+cp $R/gpurun_out/roof2/summary.txt $E/roofline_pmc_summary.txt; cp $R/gpurun_out/roof2/roofline_traffic.json $E/roofline_traffic.json
+for M in fp32 bf16x3 half; do f=$(find $R/gpurun_out/roof2/$M/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $E/roofline_only_${M}_kernel_stats.csv; done
+cp $E/roofline_traffic.json $R/profiles/roofline_traffic.json
+cd $R
 timeout 900 python bench.py > $E/bench_n1.log 2>&1; tail -1 $E/bench_n1.log > $E/bench_n1.json; cut -c1-260 $E/bench_n1.json
 timeout 600 python bench.py --no-cpu-baseline --conv-math fp32 2>&1 | tail -1 > $E/bench_n1_fp32.json; cut -c1-200 $E/bench_n1_fp32.json
 timeout 600 python bench.py --no-cpu-baseline --conv-math half 2>&1 | tail -1 > $E/bench_n1_half.json; cut -c1-200 $E/bench_n1_half.json
@@ -18,7 +24,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --no-sustained --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
 cd $R
 f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 70 > $E/step_kernel_stats.txt; head -14 $E/step_kernel_stats.txt
-bash tools/gpu_roofline2.sh > $E/roofline2.log 2>&1; tail -12 $E/roofline2.log
-cp $R/gpurun_out/roof2/summary.txt $E/roofline_pmc_summary.txt; cp $R/gpurun_out/roof2/roofline_traffic.json $E/roofline_traffic.json
-for M in fp32 bf16x3 half; do f=$(find $R/gpurun_out/roof2/$M/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $E/roofline_only_${M}_kernel_stats.csv; done
 rm -rf $E/step/*.db
