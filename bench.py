@@ -318,16 +318,23 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         # leaves as planes.  Timed: exactly that launch (same kernel template, same FLOPs and algorithmic bytes as the fp32-tensor form:
         # a plane row is the 4 bytes per channel the fp32 row has), on three operand sets in rotation (360 MB: the 256 MB Infinity Cache
         # never holds a launch's operands); the fp32-tensor form of rounds 1-4 is timed beside it (`fp32_tensors_launch_ms`).
-        fsets = [(ops.pp_from_f32(x if k == 0 else torch.randn_like(x)), ops.pp_empty(batch, 256, LR_SIDE, LR_SIDE, device)) for k in range(3)]
+        # The training step's launch also leaves the LeakyReLU signs of t as 3 MB of sign words (ops._PP_SIGNS: conv2's data gradient reads
+        # those instead of t's hi plane) -- that launch is the one timed; the launch without them (inference) beside it.
+        want_signs = ops._PP_SIGNS and ops.pp_sign_words(batch, LR_SIDE, LR_SIDE, 256, device) is not None
+        fsets = [(ops.pp_from_f32(x if k == 0 else torch.randn_like(x)), ops.pp_empty(batch, 256, LR_SIDE, LR_SIDE, device),
+                  ops.pp_sign_words(batch, LR_SIDE, LR_SIDE, 256, device) if want_signs else None) for k in range(3)]
         frot = [0]
 
-        def fprop_pp():
+        def fprop_pp(signs=True):
             frot[0] = (frot[0] + 1) % 3
-            ops.conv2d_fwd_pp_raw(fsets[frot[0]][0], w, b, 0.2, out_pp=fsets[frot[0]][1])
+            ops.conv2d_fwd_pp_raw(fsets[frot[0]][0], w, b, 0.2, out_pp=fsets[frot[0]][1], signs=fsets[frot[0]][2] if signs else None)
         fprop_fn = fprop_pp
-        kf = 'conv_patch_pers_kernel<128,bias+lrelu,x planes -> t planes> (persistent tile walk), operands cold (three sets in rotation)'
+        kf = ('conv_patch_pers_kernel<128,bias+lrelu,x planes -> t planes%s> (persistent tile walk), operands cold (three sets in rotation)'
+              % (' + sign words' if want_signs else ''))
         if with_single:
             fprop_extra['fp32_tensors_launch_ms'] = round(_time_launches(lambda: ops.conv2d_fwd_raw(x, w, b, 1, 1, 0.2), 300), 4)
+            if want_signs:
+                fprop_extra['without_sign_words_launch_ms'] = round(_time_launches(lambda: fprop_pp(False), 300), 4)
     for key, kernel, fn in (
             ('fprop', kf + ': 3x3 64->256 @54x54 fprop (RAB conv1)', fprop_fn),
             ('wgrad', kw_label + ': 3x3 64->256 @54x54 wgrad (RAB conv1)', wgrad_fn)):

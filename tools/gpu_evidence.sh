@@ -20,6 +20,7 @@ timeout 900 python bench.py --workload chain 2>&1 | tail -1 > $E/bench_chain_hal
 timeout 900 python bench.py --workload chain --conv-math bf16x3 2>&1 | tail -1 > $E/bench_chain_bf16x3.json; cut -c1-300 $E/bench_chain_bf16x3.json
 BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $E/bench_n1_rccl_single_rank.json; cut -c1-200 $E/bench_n1_rccl_single_rank.json
 timeout 600 python bench.py --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_again.json; cut -c1-200 $E/bench_n1_again.json
+timeout 600 python bench.py --steps 20 --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_steps20.json; cut -c1-200 $E/bench_n1_steps20.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --no-sustained --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
 cd $R
