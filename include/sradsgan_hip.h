@@ -338,6 +338,14 @@ int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, cons
                         const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
                         int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
                         void* stream);
+/* ABI 9: the same with the gradient g at the tail's OUTPUT and the 1x1 conv's weight wc ([64][64], OIHW) instead of dz = the conv's data
+ * gradient: dz is rebuilt on the matrix cores inside the two passes that need it (split-bf16 products, fp32 accumulate) and never
+ * stored -- autograd of sradsgan.py:262,274 without the separate data-gradient launch and its 24 MB tensor. */
+int srhip_attn_tail_bwd_g(const float* g, const float* wc, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
+                          const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
+                          const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
+                          int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
+                          void* stream);
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

@@ -1258,6 +1258,7 @@ def pixel_shuffle_act(x, r, slope=None):
 
 
 _TAIL_FUSED = os.environ.get('SRHIP_TAIL_FUSED', '1') == '1'
+_TAIL_NODZ = os.environ.get('SRHIP_TAIL_NODZ', '0') == '1'        # 1 = the tail's backward rebuilds dz on the matrix cores instead of reading it (srhip_attn_tail_bwd_g): 28.5 against 34.4 us of kernel time per tail alone, but -0.8 % in the step (its 34-48 KB of LDS per block cannot share a CU with the weight-gradient kernel): off
 
 
 def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None, out_pp=None):
@@ -1292,7 +1293,10 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
     n, c, h, w = u.shape
     lib = _hip.lib()
     f32 = dict(device=u.device, dtype=torch.float32)
-    dz = conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)                              # gradient at z = m*s*u
+    # round 5 (srhip_attn_tail_bwd_g): in split-bf16 arithmetic dz is never formed in memory -- the two passes that need it rebuild it
+    # from g on the matrix cores; other arithmetic modes keep the 1x1 conv's data-gradient launch in their own arithmetic
+    nodz = _TAIL_FUSED and _TAIL_NODZ and get_conv_math() == 'bf16x3' and tuple(wc.shape) == (c, c, 1, 1)
+    dz = None if nodz else conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)            # gradient at z = m*s*u
     dwc = dbc = None
     if not skip_params:
         dwc, dbc = wgrad_for_params(wc, bc, u, g, 1, 0, has_bias, m, s)             # x operand = z, rebuilt on the fly
@@ -1319,11 +1323,18 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
         return du, (None if direct else dfc1), (None if direct else dfc2), (None if g7 is not None else dw7), dwc, dbc
     # spatial half (7x7 conv, per-pixel gate), channel half (sigmoid -> shared MLP) and the arg-max fix-up: one call
     ws = torch.empty(lib.srhip_attn_tail_bwd_fused_workspace(n, h, w, hid) // 4, **f32)
-    _hip.check(lib.srhip_attn_tail_bwd_pp(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
-                                          _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
-                                          _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
-                                          int(g7 is not None), _p(dfc1), _p(dfc2),
-                                          int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd')
+    if nodz:
+        _hip.check(lib.srhip_attn_tail_bwd_g(_p(g), _p(wc.detach().contiguous()), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
+                                             _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
+                                             _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
+                                             int(g7 is not None), _p(dfc1), _p(dfc2),
+                                             int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd_g')
+    else:
+        _hip.check(lib.srhip_attn_tail_bwd_pp(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
+                                              _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
+                                              _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
+                                              int(g7 is not None), _p(dfc1), _p(dfc2),
+                                              int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd')
     if g7 is not None:
         dw7 = None
     if direct:
