@@ -836,7 +836,9 @@ __global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __r
 // four sums into v_pk_mul_f32 / v_pk_add_f32 pairs with op_sel, and ONE half of ONE packed result for one pixel's 16 lanes (always lanes 48-63)
 // came out without the dmean term in about one launch of ten at B = 32 -- the same inputs, a data-independent pattern (tools/diag_tail.py
 // localised it: dsp and du of one pixel, one float4 component, all 16 channel quads, delta == -dmean exactly).  Keeping the products and
-// the sums apart with empty asm statements (scalar v_mul / v_add in the ISA) gave 0 mismatches in 1 900 launches.  Not understood.
+// the sums apart with empty asm statements (scalar v_mul / v_add in the ISA) gave 0 mismatches in 1 900 launches.  Not understood.  In the
+// ISA every failure was the LO result of a `v_pk_add_f32 ... op_sel:[0,1]` (lo = src0.lo + src1.hi) whose src1.hi was the HI result of a
+// v_pk_mul_f32 five instructions earlier; tail_bwd_main_kernel's `op_sel_hi:[1,0]` forms of the same expression have never shown it.
 constexpr int DZ_WL_BYTES = 4 * 2 * 2 * 64 * 16;        // [16-channel step][column tile][hi | lo][lane] x 8 halves
 
 __device__ __forceinline__ void dz_stage_weights(const float* __restrict__ wc, char* __restrict__ wl, int nthreads) {
