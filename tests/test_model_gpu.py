@@ -784,3 +784,41 @@ def test_tail_backward_without_dz_matches_the_backward_that_reads_it(shape):
     for a, b, name in zip(res[0][1:], res[1][1:], ['du', 'dskip', 'dfc1', 'dfc2', 'dw7', 'dwc', 'dbc']):
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
         assert err < 2e-5, (name, err)
+
+
+def test_compact_record_shortcuts_leave_the_training_step_bit_identical():
+    """Round 5 replaced several re-reads of large tensors by compact records or by the producing pass itself: the RAB's LeakyReLU mask
+    as sign words (ops._PP_SIGNS), VGG's max-pool arg-max records (_POOL_IDX), the head activation's sign bits in the penalty's double
+    backward (_LRELU_BITS), the BatchNorm backward's mask from the recomputed pre-activation (_BN_BWD_X) and a BatchNorm input's two
+    gradients summed by the BatchNorm backward (_BN_FOLD).  None of them changes a single bit of one full training iteration
+    (sradsgan.py:818-892): scalars and every generator / discriminator gradient equal with all of them off (the round-4 data flow)."""
+    from sradsgan_amd import ops
+    from sradsgan_amd.train_step import TrainStep
+    if ops.get_conv_math() != 'bf16x3':
+        pytest.skip('the plane-format shortcuts are split-bf16 paths')
+    B, side, scale = 6, 27, 4                       # 6 x 64 x 108 x 108 = 4.5 M elements: the head activation is large enough for the sign-bit path
+    lr = O.det_fill('rec.lr', (B, 3, side, side), 0.5, 0.5).to(DEV)
+    hr = O.det_fill('rec.hr', (B, 3, side * scale, side * scale), 0.5, 0.5).to(DEV)
+    al = O.det_fill('rec.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
+    knobs = ('_PP_SIGNS', '_POOL_IDX', '_LRELU_BITS', '_BN_BWD_X', '_BN_FOLD')
+    assert all(getattr(ops, k) for k in knobs)
+
+    def run(on):
+        old = {k: getattr(ops, k) for k in knobs}
+        for k in knobs:
+            setattr(ops, k, on)
+        try:
+            (hg, hd, hf), _ = build_pair(2, 2, scale, DEV)
+            step = TrainStep(hg, hd, hf)
+            out = step(lr, hr, al)
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().clone() for p in list(hg.parameters()) + list(hd.parameters())]
+            return torch.stack([out[k].double() for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')]).cpu(), grads
+        finally:
+            for k, v in old.items():
+                setattr(ops, k, v)
+
+    s1, g1 = run(True)
+    s0, g0 = run(False)
+    assert torch.isfinite(s1).all() and torch.equal(s1, s0)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))
