@@ -398,7 +398,8 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         if key == 'fprop':
             for k2, v2 in fprop_extra.items():
                 rec[k2] = v2
-                rec['fp32_tensors_frac'] = round(flops / (v2 * 1e-3) / 1e12 / peak, 4)
+                if k2 == 'fp32_tensors_launch_ms':
+                    rec['fp32_tensors_frac'] = round(flops / (v2 * 1e-3) / 1e12 / peak, 4)
         if key == 'wgrad':
             for k2, v2 in wgrad_extra.items():
                 rec[k2] = v2
@@ -781,13 +782,30 @@ def supervise_rank(args, worker_cmd=None, coord_dir=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     port0 = os.environ.get('MASTER_PORT', '29533')
     if coord_dir is None:
-        coord_dir = os.environ.get('BENCH_COORD_DIR') or os.path.join(tempfile.gettempdir(), 'srhip_bench_%s_%d' % (port0, os.getppid()))
+        # all ranks share the launcher as parent: its pid AND its start time (a recycled pid must not inherit a dead job's files)
+        try:
+            born = open('/proc/%d/stat' % os.getppid()).read().rsplit(')', 1)[1].split()[19]
+        except (OSError, IndexError):
+            born = '0'
+        coord_dir = os.environ.get('BENCH_COORD_DIR') or os.path.join(tempfile.gettempdir(), 'srhip_bench_%s_%d_%s' % (port0, os.getppid(), born))
     os.makedirs(coord_dir, exist_ok=True)
     first_hb_s = float(os.environ.get('BENCH_FIRST_HEARTBEAT_S', '420'))     # fresh box: the first `import torch` alone can take 2 min
     stale_s = float(os.environ.get('BENCH_HEARTBEAT_STALE_S', '150'))
     max_attempts = 1 if os.environ.get('BENCH_NO_RETRY') == '1' else 2
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] if worker_cmd is None else list(worker_cmd)
     path = lambda name: os.path.join(coord_dir, name)
+
+    def leave(code):
+        """The last supervisor to leave removes the directory (every rank marks its exit; nobody polls the files after that)."""
+        import shutil
+        try:
+            _touch(path('exit.%d' % rank))
+            if all(os.path.exists(path('exit.%d' % r)) for r in range(world)):
+                shutil.rmtree(coord_dir, ignore_errors=True)
+        except OSError:
+            pass
+        return code
+
     rc = 1
     for attempt in range(1, max_attempts + 1):
         env = dict(os.environ, BENCH_WORKER='1', BENCH_ATTEMPT=str(attempt), BENCH_HB_FILE=path('hb.%d.%d' % (attempt, rank)))
@@ -806,7 +824,7 @@ def supervise_rank(args, worker_cmd=None, coord_dir=None):
             while not os.path.exists(path('port.%d' % attempt)):
                 if time.monotonic() > t_wait:
                     print('bench.py: rank %d never saw the retry port of attempt %d' % (rank, attempt), file=sys.stderr)
-                    return 1
+                    return leave(1)
                 time.sleep(0.05)
             env['MASTER_PORT'] = open(path('port.%d' % attempt)).read().strip()
             env['MASTER_ADDR'] = '127.0.0.1'
@@ -857,13 +875,13 @@ def supervise_rank(args, worker_cmd=None, coord_dir=None):
             if rank == 0:
                 sys.stdout.write(open(out_path).read())
                 sys.stdout.flush()
-            return 0
+            return leave(0)
         print('bench.py: rank %d, attempt %d (%s exchange) ended: %s%s' % (
             rank, attempt, 'host-synchronised' if attempt > 1 else 'overlapped', why,
             '; retrying with SRHIP_DP_HOST_SYNC=1 in fresh processes' if attempt < max_attempts else ''), file=sys.stderr)
         if rc == 0:
             rc = 1
-    return rc
+    return leave(rc)
 
 
 def self_launch(args, script=None, argv=None, visible=None):
@@ -944,9 +962,8 @@ def main():
                          'or torch.distributed.run --nproc-per-node %d' % (world, args.gpus, args.gpus, args.gpus))
     if args.gpus > 1 and os.environ.get('BENCH_WORKER') != '1' and args.workload == 'train' and not args.roofline_only:
         sys.exit(supervise_rank(args))                        # this process stays GPU-free; the rank itself is its child
-    hb = Heartbeat()
-    hb()
-    import torch
+    hb = Heartbeat()            # (no beat before the imports: until the first one the supervisor allows BENCH_FIRST_HEARTBEAT_S --
+    import torch                # a fresh box's first `import torch` alone can take 2 min -- instead of the stale-heartbeat limit)
     import torch.distributed as dist
     hb()
     if not torch.cuda.is_available():

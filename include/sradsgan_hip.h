@@ -50,7 +50,9 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
  *        fast packed weights carry a third (fp16) section, SRHIP_MATH_HALF.
  * ABI 4: srhip_conv2d_wgrad_act / srhip_conv2d_wgrad_act_ok added (no existing entry point changed).
  * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace), srhip_stream_fork, srhip_conv2d_wgrad_multi (+ _ok)
- *        added (no existing entry point changed). */
+ *        added (no existing entry point changed).
+ * ABI 6-9: see the notes at the entry points they added.
+ * ABI 10: srhip_attn_tail_bwd_g REMOVED (nothing else changed). */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
@@ -338,14 +340,8 @@ int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, cons
                         const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
                         int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
                         void* stream);
-/* ABI 9: the same with the gradient g at the tail's OUTPUT and the 1x1 conv's weight wc ([64][64], OIHW) instead of dz = the conv's data
- * gradient: dz is rebuilt on the matrix cores inside the two passes that need it (split-bf16 products, fp32 accumulate) and never
- * stored -- autograd of sradsgan.py:262,274 without the separate data-gradient launch and its 24 MB tensor. */
-int srhip_attn_tail_bwd_g(const float* g, const float* wc, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
-                          const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
-                          const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
-                          int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
-                          void* stream);
+/* (ABI 10 removed srhip_attn_tail_bwd_g -- ABI 9's form that rebuilt dz = conv_transpose(g, wc) inside the passes: it was slower in the
+ * training step, off by default, and carried a sporadic wrong result that was never explained) */
 int srhip_attn_tail_bwd_channel(float* du, const float* davg, const float* dmax, const int* argmax_hw, int n, int h,
                                 int w, int c, void* stream);
 

@@ -76,7 +76,6 @@ SIGNATURES = {
     'srhip_attn_tail_bwd_fused_workspace': (_sz, [_i] * 4),
     'srhip_attn_tail_bwd': (_i, [_vp] * 14 + [_i] + [_vp] * 2 + [_i, _vp, _sz] + [_i] * 5 + [_vp]),
     'srhip_attn_tail_bwd_pp': (_i, [_vp] * 15 + [_i] + [_vp] * 2 + [_i, _vp, _sz] + [_i] * 5 + [_vp]),
-    'srhip_attn_tail_bwd_g': (_i, [_vp] * 16 + [_i] + [_vp] * 2 + [_i, _vp, _sz] + [_i] * 5 + [_vp]),
     'srhip_attn_tail_bwd_channel': (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     'srhip_cgam_workspace': (_sz, [_i, _i]),
     'srhip_cgam_fwd': (_i, [_vp] * 5 + [_sz] + [_i] * 3 + [_vp]),

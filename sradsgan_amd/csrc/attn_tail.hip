@@ -822,235 +822,6 @@ __global__ __launch_bounds__(256, 2) void attn_tail_eval_kernel(const float* __r
 }
 
 
-// ---- round 5: the tail's backward WITHOUT dz in memory ------------------------------------------------------------------------ //
-// dz = g * Wc^T -- the 1x1 conv's data gradient, a 64 x 64 product per pixel -- used to be one conv launch that wrote 24 MB which the
-// da pass and the main pass each read again.  Here both passes take g instead and rebuild dz on the matrix cores (0.76 GFLOP per pass
-// at B = 32: nothing): a wave multiplies 32 pixel rows of g, split into bf16 hi | lo as it arrives, with the split weights (fragment-
-// ordered in LDS, built once per block) -- the conv kernels' three products al*bh, ah*bl, ah*bh per 16-channel step, fp32 accumulate --,
-// parks the 32 x 64 result in a wave-private LDS tile and reads it back in the (pixel, channel quad) layout of the passes' arithmetic,
-// which is unchanged.  One launch and 48 MB of the tail's 216 MB per backward gone from the main stream's chain.
-// MEASURED (profiles/r05_step_ab.txt): 12.0 + 16.5 us for the two passes against 9.7 + 12.8 + 11.9 (data-gradient launch) alone, but the
-// step runs 0.8 % SLOWER with them -- these passes need 34-48 KB of LDS per block and so cannot share a CU with the weight-gradient
-// kernel the way the pure streaming passes do.  The host side keeps them OFF (ops._TAIL_NODZ); tests run both forms.
-// Note on the arithmetic of tail_bwd_main_g_kernel: with d = mm * gz + dmean + ... written as in tail_bwd_main_kernel, hipcc 7.2 packs the
-// four sums into v_pk_mul_f32 / v_pk_add_f32 pairs with op_sel, and ONE half of ONE packed result for one pixel's 16 lanes (always lanes 48-63)
-// came out without the dmean term in about one launch of ten at B = 32 -- the same inputs, a data-independent pattern (tools/diag_tail.py
-// localised it: dsp and du of one pixel, one float4 component, all 16 channel quads, delta == -dmean exactly).  Keeping the products and
-// the sums apart with empty asm statements (scalar v_mul / v_add in the ISA) gave 0 mismatches in 1 900 launches.  Not understood.  In the
-// ISA every failure was the LO result of a `v_pk_add_f32 ... op_sel:[0,1]` (lo = src0.lo + src1.hi) whose src1.hi was the HI result of a
-// v_pk_mul_f32 five instructions earlier; tail_bwd_main_kernel's `op_sel_hi:[1,0]` forms of the same expression have never shown it.
-constexpr int DZ_WL_BYTES = 4 * 2 * 2 * 64 * 16;        // [16-channel step][column tile][hi | lo][lane] x 8 halves
-
-__device__ __forceinline__ void dz_stage_weights(const float* __restrict__ wc, char* __restrict__ wl, int nthreads) {
-  // entry (ks, nt, lane) = the 8 values Wc[k = ks * 16 + (lane / 32) * 8 + j][c = nt * 32 + lane % 32], j = 0..7 (wc is [k][c], OIHW of a 1x1 conv)
-  for (int e = threadIdx.x; e < 4 * 2 * 64; e += nthreads) {
-    const int lane = e & 63, nt = (e >> 6) & 1, ks = e >> 7;
-    const int c = nt * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = wc[(k0 + j) * TC + c];
-    tl_bf16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 h = (__bf16)v[j];
-      hi[j] = h;
-      lo[j] = (__bf16)(v[j] - (float)h);
-    }
-    *reinterpret_cast<tl_bf16x8*>(wl + ((ks * 2 + nt) * 2 + 0) * 1024 + lane * 16) = hi;
-    *reinterpret_cast<tl_bf16x8*>(wl + ((ks * 2 + nt) * 2 + 1) * 1024 + lane * 16) = lo;
-  }
-}
-
-// One wave: dz of the 32 pixels [pix0, pix0 + 32) (rows at or past pix_end count as zero) -> the wave's LDS tile [32][64] fp32.
-__device__ __forceinline__ void dz_tile_to_lds(const float* __restrict__ g, long pix0, long pix_end, const char* __restrict__ wl,
-                                               float* __restrict__ tile) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-  const long pix = pix0 + l31;
-  const bool ok = pix < pix_end;
-  const float* row = g + (ok ? pix : pix0) * TC + kh * 8;
-  float4 a[4][2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    a[ks][0] = *reinterpret_cast<const float4*>(row + ks * 16);
-    a[ks][1] = *reinterpret_cast<const float4*>(row + ks * 16 + 4);
-    if (!ok) a[ks][0] = a[ks][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const float v[8] = {a[ks][0].x, a[ks][0].y, a[ks][0].z, a[ks][0].w, a[ks][1].x, a[ks][1].y, a[ks][1].z, a[ks][1].w};
-    tl_bf16x8 ah, al;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 h = (__bf16)v[j];
-      ah[j] = h;
-      al[j] = (__bf16)(v[j] - (float)h);
-    }
-    tl_bf16x8 bh[2], bl[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      bh[nt] = *reinterpret_cast<const tl_bf16x8*>(wl + ((ks * 2 + nt) * 2 + 0) * 1024 + lane * 16);
-      bl[nt] = *reinterpret_cast<const tl_bf16x8*>(wl + ((ks * 2 + nt) * 2 + 1) * 1024 + lane * 16);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
-  }
-  // The accumulators leave through ds_write straight from the accumulation registers.  hipcc 7.2 puts `s_nop 10` between the last MFMA and
-  // the first of those writes; on gfx950 that is not always enough: one run in ~10 at B = 32 a single tile row came out without the
-  // last product in every fourth lane (errors of 2^-9: exactly a missing lo term; tools/diag_tail.py).  32 more wait states, tied to
-  // the accumulators so that neither the MFMAs nor the writes can move across them, cost nothing next to the passes' HBM time.
-  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {                         // accumulator register i = tile row (i / 4) * 8 + (lane / 32) * 4 + i % 4, column lane % 32
-    const int r = (i >> 2) * 8 + kh * 4 + (i & 3);
-    tile[r * TC + l31] = acc[0][i];
-    tile[r * TC + 32 + l31] = acc[1][i];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private tile: the wave's own LDS writes are all it waits for
-}
-
-// B1 without dz: da[pix] = (sum_c dz * s * u) * m * (1 - m) with dz rebuilt from g (tail_bwd_da_kernel's arithmetic on it)
-__global__ __launch_bounds__(256) void tail_bwd_da_g_kernel(const float* __restrict__ g, const float* __restrict__ wc,
-                                                             const float* __restrict__ u, const float* __restrict__ s,
-                                                             const float* __restrict__ m, float* __restrict__ da, int hw, long npix) {
-  __shared__ __attribute__((aligned(16))) char wl[DZ_WL_BYTES];
-  __shared__ __attribute__((aligned(16))) float tiles[4][32 * TC];
-  dz_stage_weights(wc, wl, 256);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long pix0 = ((long)blockIdx.x * 4 + wave) * 32;
-  if (pix0 >= npix) return;
-  float* tile = tiles[wave];
-  const int pl = lane >> 4, cq = lane & 15;
-  float4 vs[8];                                           // the pass's own operands are fetched BEFORE the product: one memory round trip, not two
-  float ms[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const long pix = pix0 + it * 4 + pl;
-    const bool ok = pix < npix;
-    const long pc = ok ? pix : pix0;
-    const int b = (int)(pc / hw);
-    const float4 v = *reinterpret_cast<const float4*>(u + pc * TC + cq * 4);
-    const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
-    vs[it] = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
-    ms[it] = m[pc];
-  }
-  dz_tile_to_lds(g, pix0, npix, wl, tile);
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int r = it * 4 + pl;
-    const long pix = pix0 + r;
-    if (pix < npix) {                                     // (uniform over the 16 lanes of a pixel: the row rotations stay inside active lanes)
-      const float4 gz = *reinterpret_cast<const float4*>(tile + r * TC + cq * 4);
-      const float4 vv = vs[it];
-      float d = (gz.x * vv.x + gz.y * vv.y) + (gz.z * vv.z + gz.w * vv.w);
-      d = group16_sum(d);
-      if (cq == 0) da[pix] = d * ms[it] * (1.f - ms[it]);
-    }
-  }
-}
-
-// B3 without dz: tail_bwd_main_kernel's arithmetic on the rebuilt dz.  grid = (blocks per image (+ 1 with FOLD), B), 128 threads = two
-// waves; a block walks 64-pixel groups of ONE image (wave w: pixels 32 w .. 32 w + 31 of the group), its threads keep the ds partial of
-// their (pixel lane, channel quad) over the groups and the block sums the 8 pixel lanes in a fixed order: dsp[b][blk][c] as before.
-template <bool FOLD>
-__global__ __launch_bounds__(128) void tail_bwd_main_g_kernel(const float* __restrict__ g, const float* __restrict__ wc,
-                                                               const float* __restrict__ u, const float* __restrict__ s,
-                                                               const float* __restrict__ m, const float2* __restrict__ dpooled,
-                                                               const int* __restrict__ argc, float* __restrict__ du,
-                                                               float* __restrict__ dsp, int hw, const float* __restrict__ w7part,
-                                                               float* __restrict__ dw7, int w7blk, int acc7) {
-  __shared__ __attribute__((aligned(16))) char wl[DZ_WL_BYTES];
-  __shared__ __attribute__((aligned(16))) float tiles[2][32 * TC];
-  __shared__ float4 red[128];
-  const int b = blockIdx.y, nblk = FOLD ? gridDim.x - 1 : gridDim.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (FOLD && blockIdx.x == nblk) {                 // the extra column (slam_conv7_wgrad_reduce_kernel's sums, one wave per tap): image b's block takes taps 2 b + wave, + 2 n, ...
-    for (int t = b * 2 + wave; t < 98; t += 2 * (int)gridDim.y) {
-      float a = 0.f;
-      for (int k = lane; k < w7blk; k += 64) a += w7part[(size_t)t * w7blk + k];
-      a = wave_sum(a);
-      if (lane == 0) dw7[t] = acc7 ? dw7[t] + a : a;
-    }
-    return;
-  }
-  dz_stage_weights(wc, wl, 128);
-  __syncthreads();
-  const int pl = lane >> 4, cq = lane & 15;
-  const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float* tile = tiles[wave];
-  const long img0 = (long)b * hw;
-  for (int grp = blockIdx.x; grp * 64 < hw; grp += nblk) {
-    const int p0 = grp * 64 + wave * 32;
-    if (p0 >= hw) continue;                              // (wave-uniform)
-    float4 vs[8];                                         // the pass's own operands are fetched BEFORE the product: one memory round trip, not two
-    float ms[8];
-    float2 dps[8];
-    int as[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int p = p0 + it * 4 + pl;
-      const long pc = img0 + (p < hw ? p : p0);
-      vs[it] = *reinterpret_cast<const float4*>(u + pc * TC + cq * 4);
-      ms[it] = m[pc];
-      dps[it] = dpooled[pc];
-      as[it] = argc[pc];
-    }
-    dz_tile_to_lds(g, img0 + p0, img0 + hw, wl, tile);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = it * 4 + pl, p = p0 + r;
-      if (p < hw) {
-        const long pix = img0 + p;
-        const float4 gz = *reinterpret_cast<const float4*>(tile + r * TC + cq * 4);
-        const float4 v = vs[it];
-        const float mm = ms[it];
-        const float2 dp = dps[it];
-        const int a = as[it] - cq * 4;
-        float dmean = dp.x * (1.f / (float)TC);
-        asm volatile("" : "+v"(dmean));                     // (keeps the four sums below scalar: see the note at the kernel's head)
-        float4 d;
-        d.x = mm * gz.x;
-        d.y = mm * gz.y;
-        d.z = mm * gz.z;
-        d.w = mm * gz.w;
-        asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
-        d.x = d.x + dmean + (a == 0 ? dp.y : 0.f);
-        d.y = d.y + dmean + (a == 1 ? dp.y : 0.f);
-        d.z = d.z + dmean + (a == 2 ? dp.y : 0.f);
-        d.w = d.w + dmean + (a == 3 ? dp.y : 0.f);
-        acc.x += d.x * v.x;
-        acc.y += d.y * v.y;
-        acc.z += d.z * v.z;
-        acc.w += d.w * v.w;
-        *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = make_float4(sc.x * d.x, sc.y * d.y, sc.z * d.z, sc.w * d.w);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile's reads are done before the next group overwrites it
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (threadIdx.x < 16) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      const float4 o = red[k * 16 + cq];
-      acc.x += o.x;
-      acc.y += o.y;
-      acc.z += o.z;
-      acc.w += o.w;
-    }
-    *reinterpret_cast<float4*>(dsp + ((size_t)b * nblk + blockIdx.x) * TC + cq * 4) = acc;
-  }
-}
-
-
 extern "C" {
 
 size_t srhip_attn_tail_workspace(int n) { return (size_t)n * (SEG > TAIL_BLK ? SEG : TAIL_BLK) * TC * 3 * sizeof(float); }
@@ -1274,48 +1045,6 @@ int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, cons
   return check_launch("attn_tail_bwd");
 }
 
-
-/* ABI 9: srhip_attn_tail_bwd_pp with the gradient g at the tail's OUTPUT and the 1x1 conv's weight wc ([64][64], OIHW) in place of
- * dz = conv_transpose(g, wc): the product is rebuilt on the matrix cores inside the two passes that need it (split-bf16 products,
- * fp32 accumulate: the arithmetic of srhip_conv2d_dgrad in SRHIP_MATH_BF16X3) and never written -- the separate data-gradient launch
- * and three passes over a 24 MB tensor per tail are gone.  Everything else as srhip_attn_tail_bwd_pp (same workspace). */
-int srhip_attn_tail_bwd_g(const float* g, const float* wc, const float* u, const float* s, const float* m, const float* pooled, const int* argc,
-                          const float* avg, const float* mx, const int* argmax_hw, const float* w7, const float* fc1,
-                          const float* fc2, float* du, void* du_pp, float* dw7, int accumulate_dw7, float* dfc1, float* dfc2,
-                          int accumulate_dfc, void* workspace, size_t workspace_bytes, int n, int h, int w, int c, int hidden,
-                          void* stream) {
-  SRHIP_REQUIRE(g && wc && u && s && m && pooled && argc && avg && mx && argmax_hw && w7 && fc1 && fc2 && du && dw7 && dfc1 && dfc2,
-                "attn_tail_bwd_g: null tensor");
-  SRHIP_REQUIRE(c == TC && hidden >= 1 && hidden <= 16 && n > 0 && h > 0 && w > 0, "attn_tail_bwd_g: C must be 64, hidden <= 16");
-  SRHIP_REQUIRE(workspace && workspace_bytes >= srhip_attn_tail_bwd_fused_workspace(n, h, w, hidden), "attn_tail_bwd_g: workspace too small");
-  SRHIP_REQUIRE(((((uintptr_t)g) | ((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0, "attn_tail_bwd_g: 16-byte aligned tensors");
-  const int hw = h * w;
-  const long npix = (long)n * hw;
-  hipStream_t st = as_stream(stream);
-  float* da = static_cast<float*>(workspace);
-  float2* dpooled = reinterpret_cast<float2*>(da + npix);
-  float* dsp = da + 3 * npix;
-  float* w7part = dsp + (size_t)n * TAIL_BLK * TC;
-  const int strips = (int)cdiv(h, W7_ROWS), w7blk = n * strips;
-  float* pw1 = w7part + (size_t)w7blk * 98;
-  float* pw2 = pw1 + (size_t)n * hidden * TC;
-  float* davg = pw2 + (size_t)n * hidden * TC;
-  float* dmax = davg + (size_t)n * TC;
-  const size_t w7lds = ((size_t)W7_ROWS * w + 2 * (size_t)(W7_ROWS + 6) * (w + 6)) * sizeof(float);
-  SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd_g: image too wide for the 7x7 weight-gradient strip");
-  hipLaunchKernelGGL(tail_bwd_da_g_kernel, dim3(cdiv(npix, 128)), dim3(256), 0, st, g, wc, u, s, m, da, hw, npix);
-  const int nd7 = (int)cdiv(npix, 256);
-  hipLaunchKernelGGL(slam_conv7_bwd_kernel, dim3(nd7 + w7blk), dim3(256), w7lds, st, da, w7, reinterpret_cast<const float2*>(pooled), dpooled,
-                     w7part, h, w, npix, strips, nd7, w7blk);
-  hipLaunchKernelGGL(tail_bwd_main_g_kernel<true>, dim3(TAIL_BLK + 1, n), dim3(128), 0, st, g, wc, u, s, m, dpooled, argc, du, dsp, hw,
-                     w7part, dw7, w7blk, accumulate_dw7);
-  hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
-  const int pix_blocks = (int)cdiv(npix, 16), red_blocks = (int)cdiv(2 * hidden * TC, 256);
-  SRHIP_REQUIRE(!du_pp || (((uintptr_t)du_pp) & 15) == 0, "attn_tail_bwd_g: du_pp must be 16-byte aligned");
-  hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(pix_blocks + red_blocks), dim3(256), 0, st, du, davg, dmax, argmax_hw, hw, npix, pix_blocks,
-                     pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc, static_cast<unsigned*>(du_pp), w, srhip_pp_guard(w));
-  return check_launch("attn_tail_bwd_g");
-}
 
 size_t srhip_attn_tail_mlp_workspace(int n, int hidden) { return (size_t)n * 2 * hidden * TC * sizeof(float); }
 

@@ -417,7 +417,7 @@ using namespace srhip;
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 9; }
+int srhip_abi_version(void) { return 10; }
 
 // `to` waits for everything enqueued on `from` so far: one event record + one stream wait through a small ring of
 // timing-less events (an event can be re-recorded once the wait that used it has been ENQUEUED: hipStreamWaitEvent

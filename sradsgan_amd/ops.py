@@ -696,6 +696,9 @@ def conv2d_wgrad_pp_raw(items, accumulate=True, on_stream=None):
     n, _, h, wd = x0.shape
     lib = _hip.lib()
     xpp, ypp = int(isinstance(x0, PP)), int(isinstance(dy0, PP))
+    for it in items[1:]:
+        if int(isinstance(it[0], PP)) != xpp or int(isinstance(it[1], PP)) != ypp:
+            raise RuntimeError('conv2d_wgrad_pp: the convolutions of one launch must share their operand formats (planes / fp32)')
     mask = lib.srhip_conv2d_wgrad_pp_ok(n, h, wd, cin, cout)
     want = 4 if (xpp and ypp) else 1 if ypp else 2 if xpp else 0
     if not (mask & want):
@@ -733,20 +736,34 @@ class _PlanePool:
         capturing = _state.capturing or torch.cuda.is_current_stream_capturing()
         if capturing:
             # a stream capture: buffers the capture creates live in the graph's private pool and must not leave it, buffers from
-            # outside must not be queried (event queries are illegal while capturing): keep the two populations apart
+            # outside must not be queried (event queries are illegal while capturing): keep the two populations apart.  Inside the
+            # capture a released buffer is taken back at once and the TAKING stream waits for the events of the streams that may
+            # still read it (record + wait are both capturable: they become graph edges) -- without them the side stream's weight-
+            # gradient node and the main stream's next writer of the same buffer were unordered in the captured graph.
             key = key + ('capture',)
             q = self.free.get(key)
         if q:
             for i, (pp, evs) in enumerate(q):
-                if capturing or all(ev.query() for ev in evs):
+                if capturing:
+                    del q[i]
+                    cur = torch.cuda.current_stream()
+                    for ev in evs:
+                        cur.wait_event(ev)
+                    return pp
+                if all(ev.query() for ev in evs):
                     del q[i]
                     return pp
         self.created += 1
         return pp_empty(n, c, h, w, device)
 
+    def begin_capture(self):
+        """A new stream capture starts: buffers (and the events they carry) of an earlier capture belong to that graph."""
+        for key in [k for k in self.free if k[-1] == 'capture']:
+            del self.free[key]
+
     def put(self, pp, streams=()):
         capturing = _state.capturing or torch.cuda.is_current_stream_capturing()
-        evs = [] if capturing else [s.record_event() for s in streams]
+        evs = [s.record_event() for s in streams]
         key = (pp.n, pp.c, pp.h, pp.w, pp.buf.device.index) + (('capture',) if capturing else ())
         self.free.setdefault(key, []).append((pp, evs))
 
@@ -834,7 +851,7 @@ def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
         _launch_wgrad_pp([item], None)
         return True
     if _state.wgrad_group > 1:
-        key = ('pp', tuple(x.shape), w.shape[0], gb is not None)
+        key = ('pp', tuple(x.shape), w.shape[0], gb is not None, isinstance(x, PP), isinstance(dy, PP))   # one launch = one operand format
         q = _state.pending.setdefault(key, [])
         q.append(item + (_stream().value, _state.wgrad_seq))
         if len(q) >= 2:
@@ -1258,7 +1275,6 @@ def pixel_shuffle_act(x, r, slope=None):
 
 
 _TAIL_FUSED = os.environ.get('SRHIP_TAIL_FUSED', '1') == '1'
-_TAIL_NODZ = os.environ.get('SRHIP_TAIL_NODZ', '0') == '1'        # 1 = the tail's backward rebuilds dz on the matrix cores instead of reading it (srhip_attn_tail_bwd_g): 28.5 against 34.4 us of kernel time per tail alone, but -0.8 % in the step (its 34-48 KB of LDS per block cannot share a CU with the weight-gradient kernel): off
 
 
 def _tail_forward(u, skip, fc1_w, fc2_w, w7, wc, bc, pool=None, out_pp=None):
@@ -1293,10 +1309,7 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
     n, c, h, w = u.shape
     lib = _hip.lib()
     f32 = dict(device=u.device, dtype=torch.float32)
-    # round 5 (srhip_attn_tail_bwd_g): in split-bf16 arithmetic dz is never formed in memory -- the two passes that need it rebuild it
-    # from g on the matrix cores; other arithmetic modes keep the 1x1 conv's data-gradient launch in their own arithmetic
-    nodz = _TAIL_FUSED and _TAIL_NODZ and get_conv_math() == 'bf16x3' and tuple(wc.shape) == (c, c, 1, 1)
-    dz = None if nodz else conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)            # gradient at z = m*s*u
+    dz = conv2d_dgrad_raw(g, wc, tuple(u.shape), 1, 0)            # gradient at z = m*s*u
     dwc = dbc = None
     if not skip_params:
         dwc, dbc = wgrad_for_params(wc, bc, u, g, 1, 0, has_bias, m, s)             # x operand = z, rebuilt on the fly
@@ -1323,14 +1336,7 @@ def _tail_backward(g, u, fc1_w, fc2_w, w7, wc, bc, saved, has_bias, skip_params=
         return du, (None if direct else dfc1), (None if direct else dfc2), (None if g7 is not None else dw7), dwc, dbc
     # spatial half (7x7 conv, per-pixel gate), channel half (sigmoid -> shared MLP) and the arg-max fix-up: one call
     ws = torch.empty(lib.srhip_attn_tail_bwd_fused_workspace(n, h, w, hid) // 4, **f32)
-    if nodz:
-        _hip.check(lib.srhip_attn_tail_bwd_g(_p(g), _p(wc.detach().contiguous()), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
-                                             _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
-                                             _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
-                                             int(g7 is not None), _p(dfc1), _p(dfc2),
-                                             int(direct), _p(ws), ws.numel() * 4, n, h, w, c, hid, _stream()), 'attn_tail_bwd_g')
-    else:
-        _hip.check(lib.srhip_attn_tail_bwd_pp(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
+    _hip.check(lib.srhip_attn_tail_bwd_pp(_p(dz), _p(u), _p(s), _p(m), _p(pooled), _p(argc), _p(avg), _p(mx), _p(arg),
                                               _p(w7.detach().contiguous()), _p(fc1_w.detach().contiguous()),
                                               _p(fc2_w.detach().contiguous()), _p(du), _p(du_pp.buf) if du_pp is not None else None, _p(dw7),
                                               int(g7 is not None), _p(dfc1), _p(dfc2),
@@ -1411,6 +1417,7 @@ class _RabBlock(Function):
         x = nhwc(x)
         ctx.carry = carry              # token under which the input's other consumers stash their gradients (carry_open)
         ctx.t_pp = ctx.x_pp = ctx.signs = None
+        ctx.planes = False
         _state.last_out_pp = None
         if rab_planes_ok(x, w1, w2):
             # round 5: t stays in padded split-bf16 planes between the block's own kernels (conv1's epilogue writes them, conv2 reads
@@ -1429,6 +1436,7 @@ class _RabBlock(Function):
             out, saved = _tail_forward(u, x, fc1_w, fc2_w, w7, wc, bc, pool, out_pp=out_pp)
             _state.last_out_pp = out_pp
             ctx.t_pp, ctx.x_pp = t_pp, x_pp
+            ctx.planes = True
             ctx.save_for_backward(x, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved)
             ctx.has_b = (b1 is not None, b2 is not None, bc is not None)
             return out
@@ -1446,6 +1454,11 @@ class _RabBlock(Function):
     def backward(ctx, g):
         if ctx.t_pp is not None:
             return _RabBlock._backward_planes(ctx, g)
+        if getattr(ctx, 'planes', False):
+            # the pooled plane buffers (t, x, sign words) went back to the pool with the first backward: there is nothing to run a
+            # second one on (retain_graph) -- say so instead of unpacking saved_tensors in the fp32 path's order
+            raise RuntimeError('_RabBlock: backward called twice on the padded-plane path (its plane buffers are released by the first '
+                               'backward); run the forward again, or set SRHIP_PP_RAB=0 for a graph that is walked repeatedly')
         x, t, u, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, *saved = ctx.saved_tensors
         g = nhwc(g)
         skip = _skip_param_grads()

@@ -480,6 +480,7 @@ class TrainStep:
         if dump:
             self._graph.enable_debug_mode()
         self._capturing = ops._state.capturing = True
+        ops.plane_pool.begin_capture()
         try:
             # same arithmetic and the same per-stream program order as the eager path
             with torch.cuda.graph(self._graph):

@@ -22,9 +22,9 @@ DEV = torch.device('cuda:0')
 NAMES = ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')
 
 
-def _run(use_graph, iters, sync_at, three_streams=False):
+def _run(use_graph, iters, sync_at, three_streams=False, groups=2, blocks=1):
     from sradsgan_amd.train_step import TrainStep
-    (hg, hd, hf), _ = build_pair(2, 1, 4, DEV)
+    (hg, hd, hf), _ = build_pair(groups, blocks, 4, DEV)
     step = TrainStep(hg, hd, hf, use_graph=use_graph, overlap_wgrad=three_streams, overlap_d_step=three_streams)
     batches = [(O.det_fill('graph.lr.%d' % (i % 3), (4, 3, 24, 24), 0.5, 0.5).to(DEV),
                 O.det_fill('graph.hr.%d' % (i % 3), (4, 3, 96, 96), 0.5, 0.5).to(DEV),
@@ -82,3 +82,21 @@ def test_three_stream_capture_replays_bit_identically_to_the_three_stream_eager_
         assert not bad, ('three-stream graph differs from the ' + name, bad[:3], (graph_s[bad[0]] - other_s[bad[0]]).tolist())
         for a, b in zip(graph_w, other_w):
             assert torch.equal(a, b), name
+
+
+def test_three_stream_capture_with_recycled_plane_buffers_is_bit_identical_to_eager():
+    """with 3 RABs per group the backward hands a padded-plane buffer back to the pool (released by the weight-gradient
+    stream's launch) and takes it again for the next RAB on the main stream BEFORE the backward ends.  Eager launches order the reuse
+    by querying the release events; under capture the pool must order it with event edges (ops._PlanePool.get waits for the
+    releasing streams' events).  2 groups x 3 RABs, three streams: 1 eager warm-up + 11 replays, bit-identical to the eager step."""
+    from sradsgan_amd import ops
+    iters = 12
+    created0 = ops.plane_pool.created
+    graph_s, graph_w = _run(True, iters, {1, 5}, three_streams=True, groups=2, blocks=3)
+    eager_s, eager_w = _run(False, iters, {1, 5}, three_streams=True, groups=2, blocks=3)
+    assert ops.plane_pool.created > created0                # the planes path ran
+    assert torch.isfinite(graph_s).all()
+    bad = (graph_s != eager_s).any(dim=1).nonzero().flatten().tolist()
+    assert not bad, ('graph replay with recycled plane buffers differs from eager', bad[:3], (graph_s[bad[0]] - eager_s[bad[0]]).tolist())
+    for a, b in zip(graph_w, eager_w):
+        assert torch.equal(a, b)

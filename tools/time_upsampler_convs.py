@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from sradsgan_amd import ops
 dev = torch.device('cuda:0')
