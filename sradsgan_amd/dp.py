@@ -84,20 +84,63 @@ def share_unique_id(make_id, rank, world, generation):
     return bytes(store.get(key))
 
 
-class GradSync:
-    """The per-iteration gradient exchange and its ordering: `start(tag, flat)` launches the bucketed in-place
-    all-reduce(SUM) of a gradient arena as soon as its producers are enqueued, `finish(tag)` makes the consumer (the Adam
-    kernel of that network) wait for it; the 1/world of the mean is folded into the Adam kernel by the caller.
+class _Enqueuer:
+    """One host thread that issues the collectives in FIFO order (device path).  An RCCL enqueue can hold its calling thread until the
+    comm stream's event waits have been satisfied on the GPU (observed with a single-rank communicator in round 3: issued from the main
+    thread in the middle of a backward pass it stalled the launch queue behind it) -- from this thread the wait costs nothing: the
+    thread that enqueues the step never blocks.  Every rank submits its buckets in the same program order and the thread keeps it."""
 
-    TrainStep calls start('G') right after the generator's backward is enqueued -- its gradients are final while the
-    whole discriminator step is still running, so the exchange flies under it --, start('D') after the discriminator's
-    backward (the second one, sradsgan.py:886; the first, :639, accumulates locally), and finish('G') / finish('D')
-    in front of the two Adam launches (:858, :887).
+    def __init__(self, device):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.device = device
+        self.thread = threading.Thread(target=self._run, name='srhip-dp-enqueue', daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            fn, ticket = item
+            try:
+                ticket.result = fn()
+            except BaseException as e:                 # surfaces in finish() on the calling thread
+                ticket.error = e
+            ticket.done.set()
+
+    def submit(self, fn):
+        import threading
+        ticket = type('Ticket', (), {})()
+        ticket.done, ticket.result, ticket.error = threading.Event(), None, None
+        self.q.put((fn, ticket))
+        return ticket
+
+    def stop(self):
+        self.q.put(None)
+        self.thread.join(timeout=30.0)
+
+
+class GradSync:
+    """The per-iteration gradient exchange and its ordering: `start(tag, flat, ...)` launches the in-place all-reduce(SUM) of a
+    gradient arena -- or, with `part=`, of ONE SLICE of it: an arena may leave in several parts, each as soon as its producers are
+    enqueued --, `finish(tag)` makes the consumer (the Adam kernel of that network) wait for every part; the 1/world of the mean is
+    folded into the Adam kernel by the caller.
+
+    What TrainStep does with it (round 6, train_step._bucket_ready / _exchange_start): the generator's arena leaves in REVERSE LAYER
+    ORDER while its backward is still running -- groups 11..8 + the up-sampler when the backward has passed group 8, groups 7..4,
+    groups 3..0, then the head / multi-scale block / tail conv at the end --, each part behind an event of the main stream and one of
+    the weight-gradient stream taken at that point; the discriminator's arena after the D stream's backward (the second one,
+    sradsgan.py:886; the first, :639, accumulates locally); finish('G') / finish('D') in front of the two Adam launches (:858, :887).
+    (Rounds 2-5 sent the generator's arena in one piece after its backward: in the default schedule, where the discriminator's
+    passes run BESIDE that backward, nothing was left to hide it under.)
 
     Device tensors: the collectives are RCCL calls through the C ABI (srhip_dp_allreduce_bucket, include/sradsgan_hip.h)
-    on a dedicated HIP stream; ordering against the compute streams is by events only, the host never synchronises.
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): the arenas (G 44.3 MB, D 18.8 MB) go out as <= 32 MiB
-    buckets so the ring's reduce-scatter of one bucket overlaps the all-gather of the previous one.
+    on a dedicated HIP stream, issued by a helper thread (_Enqueuer; SRHIP_DP_THREAD=0: by the caller); ordering against the
+    compute streams is by events only, the host never synchronises.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a part
+    goes out as <= 32 MiB buckets so the ring's reduce-scatter of one bucket overlaps the all-gather of the previous one.
     CPU tensors (the gloo tests): the same object drives torch.distributed's asynchronous all_reduce.
     """
 
@@ -116,6 +159,11 @@ class GradSync:
         self.host_sync = os.environ.get('SRHIP_DP_HOST_SYNC') == '1'
         self._comm_stream = None
         self._rccl_ready = False
+        self._whole = set()          # tags whose pending exchange is a whole arena (no further part may join it)
+        self._enqueuer = None        # _Enqueuer (device path, unless SRHIP_DP_THREAD=0)
+        self.parts = []              # (tag, part, first element, elements) of every start() with part=..., in issue order (tests, tools)
+        self.timing = False          # True: the completion events of the parts carry timestamps and are kept in done_log (tools/step_timeline.py)
+        self.done_log = []           # (tag, part, event on the comm stream)
 
     @property
     def active(self):
@@ -161,6 +209,8 @@ class GradSync:
         # a normal-priority queue that wait slows the compute streams' kernels by 12 % (75.1 vs 66.6 ms per step, with or
         # without an RCCL call behind it); on a high-priority queue the step costs 66.9 ms (+0.4 %).
         self._comm_stream = torch.cuda.Stream(priority=0 if os.environ.get('SRHIP_DP_PRIO') == '0' else -1)
+        if os.environ.get('SRHIP_DP_THREAD', '1') == '1' and not self.host_sync:
+            self._enqueuer = _Enqueuer(torch.cuda.current_device())
         self._rccl_ready = True
         _COMM_USERS += 1
 
@@ -173,6 +223,9 @@ class GradSync:
         global _COMM_USERS
         if self._rccl_ready:
             from . import _hip
+            if self._enqueuer is not None:
+                self._enqueuer.stop()
+                self._enqueuer = None
             torch.cuda.synchronize()
             self._rccl_ready = False
             self._pending.clear()
@@ -182,65 +235,86 @@ class GradSync:
                 _hip.check(_hip.lib().srhip_dp_finalize(), 'dp_finalize')
 
     # ---- the exchange -------------------------------------------------------------------------------------------- #
-    def start(self, tag, flat, after=()):
-        """Launch the all-reduce of arena `flat` under the name `tag`.  `after`: the HIP streams whose already enqueued
-        work produces `flat` (default: the current stream).  Returns immediately; with one rank (and not forced) a no-op."""
-        self.trace.append(('start', tag))
+    def start(self, tag, flat, after=(), part=None, events=None):
+        """Launch the all-reduce of `flat` under the name `tag`.  `after`: the HIP streams whose already enqueued work produces
+        `flat` (default: the current stream); `events`: events already recorded on those streams instead.  `part`: None = `flat` is
+        the whole arena (a second start before finish is a caller bug); anything else names one SLICE of a bucketed exchange --
+        several starts per tag, finish(tag) waits for all of them.  Returns immediately; with one rank (and not forced) a no-op."""
+        self.trace.append(('start', tag) if part is None else ('start', tag, part))
         if not self.active:
             return
-        if tag in self._pending:
+        if tag in self._pending and (part is None or tag in self._whole):
             raise RuntimeError('GradSync.start(%r): the previous exchange of this arena was never finished' % (tag,))
+        if part is None:
+            self._whole.add(tag)
+        if part is not None:
+            self.parts.append((tag, part, flat.storage_offset(), flat.numel()))
         if flat.is_cuda and self.host_sync:
             self.init_rccl(flat.device)
-            self._deferred[tag] = (flat, [s.record_event() for s in (after or (torch.cuda.current_stream(),))])
-            self._pending[tag] = None
+            evs = list(events) if events is not None else [s.record_event() for s in (after or (torch.cuda.current_stream(),))]
+            self._deferred.setdefault(tag, []).append((flat, evs))
+            self._pending.setdefault(tag, [])
             return
         if flat.is_cuda:
             import ctypes
+            import os
             from . import _hip
             self.init_rccl(flat.device)
             lib, comm = _hip.lib(), self._comm_stream
-            for s in (after or (torch.cuda.current_stream(),)):
-                comm.wait_stream(s)                                 # event record + wait: no host synchronisation
-            import os
-            if os.environ.get('SRHIP_DP_MODE') == 'fake':           # experiment: same stream / event structure, no RCCL call
-                with torch.cuda.stream(comm):
-                    flat[:64].mul_(1.0)
-            else:
-                for b in self.buckets(flat):
-                    _hip.check(lib.srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
-                                                             ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
-            self._pending[tag] = comm.record_event()
+            evs = list(events) if events is not None else [s.record_event() for s in (after or (torch.cuda.current_stream(),))]
+            fake = os.environ.get('SRHIP_DP_MODE') == 'fake'        # experiment: same stream / event structure, no RCCL call
+            timing = self.timing
+
+            def enqueue():
+                for ev in evs:
+                    comm.wait_event(ev)                             # no host synchronisation
+                if fake:
+                    with torch.cuda.stream(comm):
+                        flat[:64].mul_(1.0)
+                else:
+                    for b in self.buckets(flat):
+                        _hip.check(lib.srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
+                                                                 ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
+                done = torch.cuda.Event(enable_timing=timing)
+                done.record(comm)
+                if timing:
+                    self.done_log.append((tag, part, done))
+                return done
+            entry = self._enqueuer.submit(enqueue) if self._enqueuer is not None else enqueue()
+            self._pending.setdefault(tag, []).append(entry)
         else:
             if not dist.is_initialized():
                 raise RuntimeError('GradSync: torch.distributed is not initialised')
-            self._pending[tag] = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                                  for b in self.buckets(flat)]
+            self._pending.setdefault(tag, []).extend(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                                                     for b in self.buckets(flat))
 
     def finish(self, tag):
-        """Order everything enqueued afterwards on the current stream behind the exchange `tag`."""
+        """Order everything enqueued afterwards on the current stream behind every part of the exchange `tag`."""
         self.trace.append(('finish', tag))
+        self._whole.discard(tag)
         if tag in self._deferred:                                   # host_sync mode: produce, exchange, consume -- serially
             import ctypes
             from . import _hip
-            flat, events = self._deferred.pop(tag)
             self._pending.pop(tag, None)
-            for ev in events:
-                ev.synchronize()
             comm = self._comm_stream
-            for b in self.buckets(flat):
-                _hip.check(_hip.lib().srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
-                                                                ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
+            for flat, events in self._deferred.pop(tag):
+                for ev in events:
+                    ev.synchronize()
+                for b in self.buckets(flat):
+                    _hip.check(_hip.lib().srhip_dp_allreduce_bucket(ctypes.c_void_p(b.data_ptr()), b.numel(),
+                                                                    ctypes.c_void_p(comm.cuda_stream)), 'dp_allreduce_bucket')
             comm.synchronize()
             return
-        pending = self._pending.pop(tag, None)
-        if pending is None:
-            return
-        if isinstance(pending, list):
-            for h in pending:
-                h.wait()
-        else:
-            torch.cuda.current_stream().wait_event(pending)
+        for entry in self._pending.pop(tag, None) or ():
+            if hasattr(entry, 'done'):                              # a ticket of the enqueue thread: wait (on the host) until the
+                entry.done.wait()                                   # collective has been ISSUED, then order the stream behind it
+                if entry.error is not None:
+                    raise entry.error
+                entry = entry.result
+            if isinstance(entry, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(entry)
+            else:
+                entry.wait()                                        # torch.distributed work handle (CPU tensors)
 
     @property
     def grad_scale(self):

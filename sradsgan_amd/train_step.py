@@ -9,10 +9,14 @@ Structure (MI355X-first, not the reference's call order):
               become parallel branches of the graph) and replayed per iteration: the host enqueues a step in ~15 ms
               instead of 30 - 45 -- but ROCm 7.0's graph executor replays multi-branch graphs slower than the eager
               streams run them (99 vs 63 ms), so eager stays the default.
-  exchange  = in-place bucketed all-reduce of the G and D gradient arenas over RCCL (only with
-              world_size > 1; sradsgan_amd/dp.py GradSync) on its own HIP stream: G's arena is sent as soon as
-              the generator's backward is enqueued and travels under the whole discriminator step, D's after
-              the discriminator's backward; the two Adam launches wait on the matching events.  (Replayed from a graph
+  exchange  = in-place all-reduce of the G and D gradient arenas over RCCL (only with world_size > 1;
+              sradsgan_amd/dp.py GradSync) on its own HIP stream.  G's arena leaves in parts, in REVERSE LAYER ORDER, while
+              the generator's backward is still running (round 6): groups 11..8 + the up-sampler as soon as the backward has
+              passed group 8 (a tensor hook on that group's input), groups 7..4, groups 3..0, the head / multi-scale block /
+              tail conv at the end; each part waits for an event of the main stream and one of the weight-gradient stream
+              recorded at that point.  D's arena follows the D stream's backward.  The two Adam launches wait on the parts'
+              events.  (In rounds 2-5 the G arena left in one piece after the backward; with the discriminator's passes running
+              BESIDE that backward -- the default since round 3 -- nothing was left to hide it under.  Replayed from a graph
               both arenas go out after the replay: the collectives stay outside the capture.)
   update    = one fused Adam kernel per network over its flat arena (srhip_adam_step), the D one
               also applying the weight clip (:891-892).
@@ -105,6 +109,12 @@ class TrainStep:
         self._calls = 0
         self._static = None
         self._d_params = self.arena_D.params
+        self._g_parts, self._g_rest = self._plan_g_parts(int(os.environ.get('SRHIP_DP_PARTS', '3')))
+        self._parts_armed = False
+        self._parts_sent = set()
+        self._main = None
+        for k, grp in self._part_groups:
+            grp.register_forward_hook(self._make_part_hook(k))
         for p in self.F.parameters():
             p.requires_grad_(False)                      # never in an optimiser (sradsgan.py:724-725)
         ops.mark_static(self.F)
@@ -181,9 +191,82 @@ class TrainStep:
             with ops.bn_fold_second_order():        # (the penalty term: a BatchNorm input's two gradients are summed by the BatchNorm backward itself)
                 torch.autograd.backward(t, inputs=inputs)
 
-    def _exchange_start(self, which):
-        """Hands a finished gradient arena to the exchange (dp.GradSync.start): called right after the backward that
-        completes it has been ENQUEUED; the collective waits on events of the streams that produce the arena."""
+    def _plan_g_parts(self, nparts, any_device=False):
+        """The generator's gradient arena as the parts its backward completes, in that order (dp.GradSync, `part=`).
+
+        Arena order = registration order: conv1 | res_groups[0..n) | GAB_UP | MSB | conv3; the backward finishes conv3 and GAB_UP
+        first, then the groups n-1 .. 0, then the multi-scale block and the head conv.  Part k (k = 0 .. nparts-1) = the groups
+        [b_k, b_(k-1)) with b_k = n (nparts-1-k) / nparts -- part 0 also takes GAB_UP, contiguous behind the last group -- and is
+        handed over when the gradient at the INPUT of group b_k exists (a tensor hook registered by a forward hook of that group).
+        Everything else -- conv1, MSB, conv3: 0.3 MB -- leaves with the end of the backward.  Returns ([(first, end) per part],
+        [(first, end) of the rest]) in elements; self._part_groups = [(k, group module)]."""
+        self._part_groups = []
+        arena = self.arena_G
+        groups = getattr(self.G, 'res_groups', None)
+        if nparts < 1 or groups is None or len(groups) < 2 or not (arena.flat_g.is_cuda or any_device):
+            return [], [(0, arena.numel)]
+        off = {id(p): o for p, o in zip(arena.params, arena.offsets)}
+        first_of = []
+        for grp in groups:
+            ps = list(grp.parameters())
+            if not ps or id(ps[0]) not in off:
+                return [], [(0, arena.numel)]
+            first_of.append(off[id(ps[0])])
+        if first_of != sorted(first_of):
+            return [], [(0, arena.numel)]
+        n = len(groups)
+        tail_of_groups = arena.numel                            # first element behind the last group's parameters ...
+        up = getattr(self.G, 'GAB_UP', None)
+        behind = [o for o in arena.offsets if o > first_of[-1] and not any(o == off[id(p)] for p in groups[-1].parameters())]
+        if behind:
+            tail_of_groups = min(behind)
+        end0 = tail_of_groups                                   # ... part 0 extends over GAB_UP when it sits right there
+        if up is not None:
+            ups = [off[id(p)] for p in up.parameters() if id(p) in off]
+            if ups and min(ups) == tail_of_groups:
+                later = [o for o in arena.offsets if o > max(ups)]
+                end0 = min(later) if later else arena.numel
+        bounds = sorted({n * (nparts - 1 - k) // nparts for k in range(nparts)}, reverse=True)      # group indices b_0 > b_1 > ... >= 0
+        parts, hi = [], end0
+        for k, b in enumerate(bounds):
+            parts.append((first_of[b], hi))
+            self._part_groups.append((k, groups[b]))
+            hi = first_of[b]
+        rest = [(0, hi)] if hi > 0 else []
+        if end0 < arena.numel:
+            rest.append((end0, arena.numel))
+        return parts, rest
+
+    def _make_part_hook(self, k):
+        def on_forward(module, inputs, output):
+            x = inputs[0] if inputs else None
+            if self._parts_armed and torch.is_tensor(x) and x.requires_grad:
+                x.register_hook(lambda grad: self._bucket_ready(k))    # fires when the whole group's backward has been enqueued
+        return on_forward
+
+    def _bucket_ready(self, k):
+        """Part k of the generator's arena is final once everything enqueued so far has run: hand it to the exchange behind an event
+        of the main stream and one of the weight-gradient stream.  Runs on autograd's device thread, in the middle of the backward."""
+        gs = self.grad_sync
+        if not self._parts_armed or k in self._parts_sent or gs is None or not gs.active:
+            return
+        self._parts_sent.add(k)
+        ops.flush_pending_wgrads()              # (group boundaries are pair boundaries of the RAB weight gradients: nothing of theirs is held)
+        flat = self.arena_G.flat_g
+        evs = []
+        if flat.is_cuda:
+            evs.append(self._main.record_event())
+            if self.overlap_wgrad and self._wgrad_stream is not None:
+                evs.append(self._wgrad_stream.record_event())
+        lo, hi = self._g_parts[k]
+        gs.start('G', flat[lo:hi], events=evs, part=k)
+        if flat.is_cuda:
+            self._mark('G part %d handed to the exchange (main)' % k, self._main)
+
+    def _exchange_start(self, which, producers=None):
+        """Hands a finished gradient arena -- for the generator: what its parts have not taken yet -- to the exchange
+        (dp.GradSync.start): called right after the backward that completes it has been ENQUEUED; the collective waits on events
+        of the streams that produce the arena."""
         ops.flush_pending_wgrads()              # grouped weight gradients still waiting for a partner go out now
         gs = self.grad_sync
         if gs is None or not gs.active or self._capturing:
@@ -192,6 +275,16 @@ class TrainStep:
         streams = [torch.cuda.current_stream()] if arena.flat_g.is_cuda else []
         if arena.flat_g.is_cuda and self.overlap_wgrad and self._wgrad_stream is not None:
             streams.append(self._wgrad_stream)                    # the weight-gradient kernels run there
+        if producers is not None and arena.flat_g.is_cuda:
+            streams = list(producers)                             # the caller knows which streams complete this arena
+        if which == 'G' and getattr(self, '_parts_armed', False):
+            self._parts_armed = False
+            evs = [s.record_event() for s in streams]
+            todo = [(k, r) for k, r in enumerate(self._g_parts) if k not in self._parts_sent]       # (a hook that never fired: its part leaves now)
+            todo += [(len(self._g_parts) + i, r) for i, r in enumerate(self._g_rest)]
+            for k, (lo, hi) in todo:
+                gs.start('G', arena.flat_g[lo:hi], events=evs, part=k)
+            return
         gs.start(which, arena.flat_g, after=streams)
 
     def _compute_onewalk(self, imgs_lr, imgs_hr, alpha):
@@ -215,7 +308,10 @@ class TrainStep:
         G, D, F = self.G, self.D, self.F
         g_params, d_params = self.arena_G.params, self.arena_D.params
         side, dside = self._wgrad_stream, self._d_stream
-        main = torch.cuda.current_stream()
+        main = self._main = torch.cuda.current_stream()
+        gs = self.grad_sync
+        self._parts_sent = set()
+        self._parts_armed = bool(self._g_parts) and gs is not None and gs.active and not self._capturing and not gs.host_sync
         self._set_d_grad(True)
         self.arena_G.zero_grad()
         self.arena_D.zero_grad()
@@ -274,11 +370,14 @@ class TrainStep:
         self._exchange_start('G')
         self._mark('G bwd done (main)')
         self._mark('wgrads done (wgrad stream)', side)
+        # D's arena is complete with the D stream's backward (which waited for the fake term's contributions: walked_main / walked_side);
+        # its collective is ISSUED here, behind the generator's parts (one communicator: same order on every rank), but waits only for
+        # the D stream -- not for the end of the generator's backward on the main stream
+        self._exchange_start('D', producers=[dside])
         main.wait_stream(dside)
         _join_side(main, side)
         for t in (loss_D, gp):
             t.record_stream(main)
-        self._exchange_start('D')
         out = dict(loss_G=loss_G, loss_D=loss_D, pixel=pixel.detach(), content=content.detach(), loss_gan=loss_gan,
                    gp=gp.detach(), gen_hr=fake)
         if os.environ.get('SRHIP_STEP_DEBUG') == '1':

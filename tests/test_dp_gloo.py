@@ -95,6 +95,61 @@ def test_exchange_ordering_world2(tmp_path):
     assert [open(os.path.join(str(tmp_path), 'ord%d' % r)).read() for r in range(2)] == ['1', '1']
 
 
+def _parts_worker(rank, world, port, out_dir):
+    """Round 6: the generator's arena leaves in parts, in reverse layer order, driven by TrainStep's own plan and hand-over code
+    (train_step.TrainStep._plan_g_parts / _bucket_ready / _exchange_start) on the real generator's parameter layout: the parts are
+    disjoint, cover the arena exactly once, go out late layers first, in the same order on every rank, and finish('G') leaves the
+    sum over ranks everywhere."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sradsgan_amd import model as M
+    from sradsgan_amd import train_step as ts
+    from sradsgan_amd.dp import GradSync, ParamArena, broadcast_module
+    torch.manual_seed(3)
+    G = M.GeneratorResNet(M.ResGroup, n_residual_blocks=6, n_basic_blocks=1, upscale_factor=2)
+    broadcast_module(G, 0)
+    step = ts.TrainStep.__new__(ts.TrainStep)
+    step.G, step.arena_G = G, ParamArena(G)
+    step.grad_sync = sync = GradSync(world, bucket_bytes=64 << 10)
+    step._capturing, step.overlap_wgrad, step._wgrad_stream, step._timeline_on = False, False, None, False
+    step._g_parts, step._g_rest = step._plan_g_parts(3, any_device=True)
+    ok = len(step._g_parts) == 3 and [k for k, _ in step._part_groups] == [0, 1, 2]
+    names = {id(p): n for n, p in G.named_parameters()}
+    first = lambda lo: names[id(step.arena_G.params[step.arena_G.offsets.index(lo)])]
+    ok = ok and [first(lo) for lo, _ in step._g_parts] == ['res_groups.4.RG.0.conv1.weight', 'res_groups.2.RG.0.conv1.weight', 'res_groups.0.RG.0.conv1.weight']
+    last0 = max(o for o in step.arena_G.offsets if o < step._g_parts[0][1])
+    ok = ok and names[id(step.arena_G.params[step.arena_G.offsets.index(last0)])].startswith('GAB_UP.')     # the up-sampler rides with the last groups
+    flat = step.arena_G.flat_g
+    torch.manual_seed(20 + rank)
+    flat.copy_(torch.randn(flat.numel()))                  # "the backward's result", different on every rank
+    local = flat.clone()
+    step._parts_sent, step._parts_armed = set(), True
+    for k in range(3):                                     # the tensor hooks fire in this order: late groups first
+        step._bucket_ready(k)
+    step._bucket_ready(1)                                  # a hook that fires twice hands nothing over twice
+    step._exchange_start('G')                              # the end of the backward: what is left
+    sync.finish('G')
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    ok = ok and torch.allclose(flat, sum(both), rtol=1e-6, atol=1e-6)
+    spans = sorted((lo, lo + n) for _, _, lo, n in sync.parts)
+    ok = ok and spans[0][0] == 0 and spans[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    ok = ok and [p for _, p, _, _ in sync.parts] == [0, 1, 2, 3, 4]
+    ok = ok and [lo for _, _, lo, _ in sync.parts][:3] == sorted([lo for _, _, lo, _ in sync.parts][:3], reverse=True)
+    order = [None] * world
+    dist.all_gather_object(order, sync.parts)
+    ok = ok and order[0] == order[1] and not sync._pending
+    open(os.path.join(out_dir, 'parts%d' % rank), 'w').write('1' if ok else '0')
+    dist.destroy_process_group()
+
+
+def test_generator_arena_leaves_in_reverse_layer_order_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_parts_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(os.path.join(str(tmp_path), 'parts%d' % r)).read() for r in range(2)] == ['1', '1']
+
+
 def _id_worker(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -130,7 +185,7 @@ def test_train_step_drives_the_exchange_in_that_order():
     from sradsgan_amd.dp import GradSync
     calls = []
     sync = GradSync(2)
-    sync.start = lambda tag, flat, after=(): calls.append(('start', tag))
+    sync.start = lambda tag, flat, after=(), part=None, events=None: calls.append(('start', tag))
     sync.finish = lambda tag: calls.append(('finish', tag))
     step = ts.TrainStep.__new__(ts.TrainStep)
     step.grad_sync, step._capturing, step.use_graph, step._graph = sync, False, False, None

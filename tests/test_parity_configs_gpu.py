@@ -214,8 +214,8 @@ def _trajectory(scale, lr_side, batch, sync, iters):
 
 def test_forced_single_rank_rccl_exchange_is_bit_identical_to_the_plain_step():
     """The N > 1 code path on one GPU: dp.GradSync(force=True) sends both gradient arenas through a one-rank RCCL
-    communicator (srhip_dp_allreduce_bucket) on its own high-priority stream, G's under the discriminator step, ordered by
-    events only.  A one-rank all-reduce(SUM) is the identity and grad_scale is 1, so ANY difference from the plain step is
+    communicator (srhip_dp_allreduce_bucket) on its own high-priority stream -- G's in parts handed over by tensor hooks while its
+    backward is still being enqueued, the collectives issued by the enqueue thread --, ordered by events only.  A one-rank all-reduce(SUM) is the identity and grad_scale is 1, so ANY difference from the plain step is
     an ordering bug (an arena read before its producers finished, an Adam launch that did not wait).  Two models in one
     process (the second one re-uses the process-wide communicator), 24 iterations each."""
     from sradsgan_amd import dp
@@ -228,7 +228,16 @@ def test_forced_single_rank_rccl_exchange_is_bit_identical_to_the_plain_step():
             syncs.append(sync)
             rccl_s, rccl_w = _trajectory(scale, lr_side, batch, sync, iters)
             assert sync.rccl_ranks() == 1
-            assert [t for t in sync.trace[:4]] == [('start', 'G'), ('start', 'D'), ('finish', 'G'), ('finish', 'D')]
+            # round 6: the generator's arena leaves in parts from inside its backward -- late layers first (2 groups: group 1 + the
+            # up-sampler, group 0, then head and multi-scale block / tail conv) --, the discriminator's arena behind them
+            per = sync.trace.index(('finish', 'D')) + 1
+            head = sync.trace[:per]
+            assert [t for t in head if len(t) == 3] == [('start', 'G', k) for k in range(4)], head
+            assert head[-3:] == [('start', 'D'), ('finish', 'G'), ('finish', 'D')], head
+            first = [lo for _, _, lo, _ in sync.parts[:2]]
+            assert first[0] > first[1] > 0
+            spans = sorted((lo, lo + n) for _, _, lo, n in sync.parts[:4])
+            assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             assert torch.isfinite(plain_s).all()
             bad = (plain_s != rccl_s).any(dim=1).nonzero().flatten().tolist()
             assert not bad, ('x%d: exchange changes the trajectory; first differing iterations' % scale, bad[:3],
