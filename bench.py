@@ -88,6 +88,9 @@ def parse():
     ap.add_argument('--no-sustained', action='store_true',
                     help='skip the 1.2 s power / clock sampling loops of the roofline kernels (profiler runs: keeps the per-dispatch '
                          'statistics to the timed launches)')
+    ap.add_argument('--step-only', action='store_true',
+                    help='the timed steps and nothing else: no roofline section, no in-step probe steps, no fp32 line, no CPU baseline '
+                         '(A/B runs; profiler runs whose per-kernel table must be the step only).  The line then carries no roofline: not the contract line')
     ap.add_argument('--trace-losses', action='store_true', help='print every step\'s losses to stderr (debug)')
     return ap.parse_args()
 
@@ -1060,7 +1063,7 @@ def main():
     # The same job with the conv contraction in exact fp32 (a short extra run after the timed region, every rank takes
     # part): reported next to the headline so both arithmetic modes are in one line
     alt = None
-    if conv_math == 'bf16x3' and not args.no_fp32_line:
+    if conv_math == 'bf16x3' and not args.no_fp32_line and not args.step_only:
         ops.set_conv_math('fp32')
         for _ in range(max(2, args.warmup)):
             step(lr, hr, alpha)
@@ -1083,7 +1086,7 @@ def main():
     # the library's probe armed on rank 0.  EVERY rank runs these steps -- with N > 1 each step carries the RCCL all-reduces of the
     # gradient exchange, and a rank that sat in the final barrier instead would leave rank 0's collectives unmatched for ever.
     probes = {}
-    if not _use_graph(args) and B == PER_GPU_BATCH:
+    if not _use_graph(args) and B == PER_GPU_BATCH and not args.step_only:
         for key, kind in (('roofline', 1), ('roofline_wgrad', 3)):
             probes[key] = (kind,) + tuple(in_step_probe(lambda: step(lr, hr, alpha), B, kind, armed=(rank == 0)))
         barrier()
@@ -1110,13 +1113,20 @@ def main():
             line['rccl_ranks'] = sync.rccl_ranks()             # size of the communicator the gradients really went through
             if line['rccl_ranks'] != world:
                 raise SystemExit('bench.py: the gradients went through a communicator of %d ranks, the job has %d' % (line['rccl_ranks'], world))
-            line['exchange'] = 'srhip_dp_allreduce_bucket on a dedicated HIP stream, G arena under the D step'
+            line['exchange'] = ('srhip_dp_allreduce_bucket on a dedicated HIP stream; G arena in %d parts in reverse layer order from inside its '
+                                'backward, D arena behind the D stream' % len({p for t, p, _, _ in sync.parts if t == 'G'}) if sync.parts
+                                else 'srhip_dp_allreduce_bucket on a dedicated HIP stream; each arena in one piece after its backward')
+            line['exchange_issued_by'] = 'enqueue thread' if sync._enqueuer is not None else 'calling thread'
             line['exchange_mode'] = ('host-synchronised (SRHIP_DP_HOST_SYNC=1: produce, exchange, consume serially)' if sync.host_sync
                                      else 'overlapped (collectives enqueued ahead of their inputs, ordered by events)')
             line['launch_attempt'] = int(os.environ.get('BENCH_ATTEMPT', '1'))
         if alt is not None:
             line['exact_fp32_mode'] = alt
-        line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B, not args.no_sustained)
+        if args.step_only:
+            line['roofline'] = line['roofline_wgrad'] = None
+            line['note'] = '--step-only: no roofline section in this run'
+        else:
+            line['roofline'], line['roofline_wgrad'] = time_dominant_kernel(device, B, not args.no_sustained)
         peak = MATH_PEAK[conv_math][0]
         conv_flops = 2.0 * B * LR_SIDE * LR_SIDE * 256 * 64 * 9
         for key, (kind, ms_conv, calls, convs) in probes.items():
@@ -1128,7 +1138,7 @@ def main():
                 line[key]['in_step_note'] = ('HIP events around every %s call of this geometry on its launch stream during 4 extra training steps '
                                              'after the timed region (srhip_probe_*): the other two streams of the step share the chip'
                                              % ('fprop' if kind == 1 else 'weight-gradient'))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.step_only:
             line['cpu_baseline'] = cpu_baseline_subprocess(args.cpu_iters)
     if world > 1 or force_dist:
         dist.barrier()

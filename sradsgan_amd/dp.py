@@ -249,6 +249,9 @@ class GradSync:
             self._whole.add(tag)
         if part is not None:
             self.parts.append((tag, part, flat.storage_offset(), flat.numel()))
+        for log in (self.trace, self.parts, self.done_log):         # diagnostics, not history: bounded over a long run
+            if len(log) > 8192:
+                del log[:-4096]
         if flat.is_cuda and self.host_sync:
             self.init_rccl(flat.device)
             evs = list(events) if events is not None else [s.record_event() for s in (after or (torch.cuda.current_stream(),))]
