@@ -737,9 +737,13 @@ class _PlanePool:
         if capturing:
             # a stream capture: buffers the capture creates live in the graph's private pool and must not leave it, buffers from
             # outside must not be queried (event queries are illegal while capturing): keep the two populations apart.  Inside the
-            # capture a released buffer is taken back at once and the TAKING stream waits for the events of the streams that may
-            # still read it (record + wait are both capturable: they become graph edges) -- without them the side stream's weight-
-            # gradient node and the main stream's next writer of the same buffer were unordered in the captured graph.
+            # capture a released buffer is taken back at once and the TAKING stream waits for the streams that may still read it
+            # (wait_stream = record + wait, the one cross-stream primitive the capture already uses everywhere: it becomes a graph
+            # edge) -- without it the side stream's weight-gradient node and the main stream's next writer of the same buffer were
+            # unordered in the captured graph.  The wait covers everything the releasing stream has enqueued so far, not
+            # just the reader: the replayed graph loses some overlap there, eager launches (the default) are not affected.
+            # (Events recorded at release time and waited for here would be tighter, but an event that is recorded inside a capture
+            # and never waited for -- a buffer nobody takes again -- crashed hipStreamEndCapture on ROCm 7.0.)
             key = key + ('capture',)
             q = self.free.get(key)
         if q:
@@ -747,14 +751,25 @@ class _PlanePool:
                 if capturing:
                     del q[i]
                     cur = torch.cuda.current_stream()
-                    for ev in evs:
-                        cur.wait_event(ev)
+                    for st in evs:                      # (under capture the entries are the releasing STREAMS)
+                        if st != cur:
+                            cur.wait_stream(st)
                     return pp
                 if all(ev.query() for ev in evs):
                     del q[i]
                     return pp
         self.created += 1
         return pp_empty(n, c, h, w, device)
+
+    def release_all(self):
+        """Drops every free buffer (after the streams that may still read them have passed their release events): a NEW model is
+        about to run -- another scale of the chain sweep, another network -- and the old geometries' buffers would otherwise stay for
+        the life of the process (chain sweep in one process: 115 -> 147 GB, profiles/r05_bench_chain_bf16x3.json)."""
+        for key, q in self.free.items():
+            for pp, evs in q:
+                for ev in evs:
+                    ev.synchronize()                   # (an event, or -- entries released inside a capture -- the stream itself)
+        self.free.clear()
 
     def begin_capture(self):
         """A new stream capture starts: buffers (and the events they carry) of an earlier capture belong to that graph."""
@@ -763,7 +778,7 @@ class _PlanePool:
 
     def put(self, pp, streams=()):
         capturing = _state.capturing or torch.cuda.is_current_stream_capturing()
-        evs = [s.record_event() for s in streams]
+        evs = list(streams) if capturing else [s.record_event() for s in streams]
         key = (pp.n, pp.c, pp.h, pp.w, pp.buf.device.index) + (('capture',) if capturing else ())
         self.free.setdefault(key, []).append((pp, evs))
 

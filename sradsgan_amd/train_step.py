@@ -109,6 +109,8 @@ class TrainStep:
         self._calls = 0
         self._static = None
         self._d_params = self.arena_D.params
+        if dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            ops.plane_pool.release_all()                 # the previous model's padded-plane buffers (other geometries) go back to the allocator
         self._g_parts, self._g_rest = self._plan_g_parts(int(os.environ.get('SRHIP_DP_PARTS', '3')))
         self._parts_armed = False
         self._parts_sent = set()

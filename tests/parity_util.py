@@ -191,6 +191,49 @@ def sibling_grad_check(net, golden, ref32, ref64, run_case, rtol=1e-3, wiring=5e
     return report
 
 
+def grad_fraction(hip_nets, ora_nets, tol, floor=1e-2):
+    """Element-wise companion of grad_score: per parameter tensor the FRACTION of elements with |dg| <= tol * max(max|g_tensor|,
+    floor * max|g_network|); returns (smallest fraction, its tensor, fraction over all elements).  What survives a flipped LeakyReLU
+    branch: one flipped unit moves the gradient entries that unit feeds (a row of one weight tensor, a few BatchNorm entries) by a
+    finite amount and leaves everything else at roundoff."""
+    worst, worst_key, inside, total = 1.0, '', 0, 0
+    for hn, on in zip(hip_nets, ora_nets):
+        og = {k: p.grad for k, p in on.named_parameters() if p.grad is not None}
+        if not og:
+            continue
+        net_scale = max(float(g.abs().max()) for g in og.values())
+        for k, p in hn.named_parameters():
+            if k in og and p.grad is not None and not k.endswith(ZERO_GRAD_KEYS):
+                d = (p.grad.detach().cpu().double() - og[k].double()).abs()
+                bar = tol * max(float(og[k].abs().max()), floor * net_scale, 1e-30)
+                ok = int((d <= bar).sum())
+                inside, total = inside + ok, total + d.numel()
+                if ok / d.numel() < worst:
+                    worst, worst_key = ok / d.numel(), k
+    return worst, worst_key, inside / max(total, 1)
+
+
+def closest_deep_preactivation(tag, n_groups, n_blocks, batch, lr_side, scale):
+    """min |LeakyReLU input| over the discriminator's deep layers (tensors of <= 10000 elements) in the oracle's first iteration on the
+    inputs of `tag` (CPU, implementation-independent): the quantity well_conditioned_tag thresholds."""
+    import torch.nn as nn
+    og = O.GeneratorResNet(O.ResGroup, n_residual_blocks=n_groups, n_basic_blocks=n_blocks, upscale_factor=scale)
+    od, of = O.Discriminator(), O.FeatureExtractor()
+    O.det_init_(og, prefix='G.'), O.det_init_(od, prefix='D.'), O.det_init_(of, prefix='F.')
+    closest = [1.0]
+    hooks = [m.register_forward_hook(
+        lambda mod, inp, out: closest.append(float(inp[0].detach().abs().min())) if inp[0].numel() <= 10000 else None)
+        for m in od.modules() if isinstance(m, nn.LeakyReLU)]
+    lr_img = O.det_fill('%s.lr.0' % tag, (batch, 3, lr_side, lr_side), 0.5, 0.5)
+    hr_img = O.det_fill('%s.hr.0' % tag, (batch, 3, lr_side * scale, lr_side * scale), 0.5, 0.5)
+    alpha = O.det_fill('%s.alpha.0' % tag, (batch, 1, 1, 1), 0.5, 0.5)
+    O.train_step(og, od, of, torch.optim.Adam(og.parameters(), lr=2e-4), torch.optim.Adam(od.parameters(), lr=2e-4),
+                 lr_img, hr_img, alpha)
+    for h in hooks:
+        h.remove()
+    return min(closest)
+
+
 def well_conditioned_tag(base, n_groups, n_blocks, batch, lr_side, scale, margin=1e-5, candidates='abcdef'):
     """An input tag for train_parity whose FIRST iteration keeps the discriminator's deepest LeakyReLU inputs (tensors
     of <= 10000 elements, normalised by a BatchNorm over 8-32 samples) at least `margin` away
