@@ -529,6 +529,12 @@ def run_inference(args, device):
         out = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    roof = None
+    if not args.step_only:
+        # the workload's dominant kernel in isolation at THIS batch (RAB conv1 fprop, 36 of the forward's 78 conv launches): at B = 16 a
+        # launch has 768 tiles of the 128-wide walk for 768 block slots, the 64-channel convs 384 -- half a wave of blocks
+        roof, _ = time_dominant_kernel(device, B, not args.no_sustained, with_single=False)
+        roof['whole_job_frac_of_mfma_peak'] = round(B * args.steps / dt * 69.19 / 1e3 / MATH_PEAK[ops.get_conv_math()][0], 4)
     print(json.dumps({'metric': 'generator inference images/sec (54x54 -> 216x216, x4) incl. device PSNR/SSIM/ERGAS',
                       'value': round(B * args.steps / dt, 2), 'unit': 'img/s', 'n_gpus': 1, 'steps': args.steps,
                       'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
@@ -536,7 +542,7 @@ def run_inference(args, device):
                       'config': {'workload': 'SRADSGAN generator-only x4 inference, batch %d' % B,
                                  'conv_math': ops.get_conv_math(), 'launch': 'eager' if args.no_graph else 'hipGraph'},
                       'gflop_per_image': 69.19, 'tflops': round(B * args.steps / dt * 69.19 / 1e3, 2),
-                      'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4)}), flush=True)
+                      'mean_psnr_vs_random_target': round(float(out['sr']['psnr'].mean()), 4), 'roofline': roof}), flush=True)
 
 
 def _use_graph(args):

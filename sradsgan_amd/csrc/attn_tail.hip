@@ -426,6 +426,107 @@ __global__ void tail_bwd_main_kernel(const float* __restrict__ dz, const float* 
   }
 }
 
+// ---- B3' (round 6): the main pass WITH the 7x7 conv's data gradient inside -------------------------------------------------------- //
+// slam_conv7_bwd_kernel sat in every tail's serial chain between the da pass and this one (8 us alone, 18 us inside the training step:
+// its launch waits for block slots like every other) only to turn da into dpooled = conv_transpose7x7(da, w7) -- 98 multiply-adds per
+// pixel on a 4-byte-per-pixel map.  Here a block owns a CONTIGUOUS range of 16-pixel groups of one image, stages the da rows of that
+// range plus the 3-row / 3-column halo in LDS (zero outside the image) and the 16 lanes that share a pixel split the 49 taps between
+// them (lane q: taps q, q + 16, q + 32, q + 48; one LDS read serves both channels of the pooled map), group16_sum gives every lane
+// dpooled of its pixel.  The rest is tail_bwd_main_kernel.  The grid's extra block columns [nblk, nblk + strips) run the 7x7 conv's
+// weight-gradient strips (slam_conv7_wgrad_block, unchanged); their partials are summed by extra blocks of tail_bwd_fix_kernel
+// (w7part != nullptr there), in slam_conv7_wgrad_reduce_kernel's order.  dpooled differs from slam_conv7_dgrad_block's by summation
+// order only (16 lane partials of <= 4 taps instead of one chain of 49).
+__global__ __launch_bounds__(256) void tail_bwd_main2_kernel(const float* __restrict__ dz, const float* __restrict__ u,
+                                                              const float* __restrict__ s, const float* __restrict__ m,
+                                                              const float* __restrict__ da, const float* __restrict__ w7,
+                                                              const float2* __restrict__ pooled, const int* __restrict__ argc,
+                                                              float* __restrict__ du, float* __restrict__ dsp, float* __restrict__ w7part,
+                                                              int h, int w, int nblk, int strips, int gpb, int tile_rows) {
+  extern __shared__ __attribute__((aligned(16))) float w7lds[];
+  __shared__ float4 red[256];
+  const int b = blockIdx.y, hw = h * w;
+  if ((int)blockIdx.x >= nblk) {                      // weight-gradient strip (int)blockIdx.x - nblk of image b
+    slam_conv7_wgrad_block(da, pooled, w7part, h, w, strips, b * strips + ((int)blockIdx.x - nblk), (int)gridDim.y * strips);
+    return;
+  }
+  const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  const int ngroups = (hw + 15) >> 4;
+  const int g0 = blockIdx.x * gpb, g1 = min(g0 + gpb, ngroups);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g0 < g1) {                                      // (block-uniform)
+    // ---- da rows [ya - 3, yb + 3] x columns [-3, w + 3) of image b -> LDS, zero outside the image ----
+    const int p0 = g0 * 16, p1 = min(g1 * 16, hw);
+    const int ya = p0 / w, yb = (p1 - 1) / w;
+    const int wp = w + 6, rows = yb - ya + 7;          // <= tile_rows
+    const float* img = da + (size_t)b * hw;
+    for (int i = threadIdx.x; i < rows * wp; i += 256) {
+      const int r = i / wp, c = i - r * wp;
+      const int yy = ya - 3 + r, xx = c - 3;
+      w7lds[i] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * w + xx] : 0.f;
+    }
+    // this lane's taps: t = cq + 16 k (k = 0..3, t < 49): weight of both pooled channels and the tile offset relative to the pixel
+    float w0[4], w1[4];
+    int toff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = cq + 16 * k;
+      const bool ok = t < 49;
+      const int tt = ok ? t : 0, kh = tt / 7, kw = tt - kh * 7;
+      w0[k] = ok ? w7[tt] : 0.f;
+      w1[k] = ok ? w7[49 + tt] : 0.f;
+      toff[k] = (3 - kh) * wp + (3 - kw);              // da[(y - kh + 3, x - kw + 3)] relative to tile position of (y, x)
+    }
+    const float4 sc = *reinterpret_cast<const float4*>(s + b * TC + cq * 4);
+    __syncthreads();
+    for (int grp = g0; grp < g1; ++grp) {
+      const int p = grp * 16 + pl;
+      const bool ok = p < hw;                          // (uniform over the 16 lanes of a pixel)
+      const int pc = ok ? p : p0;
+      const int y = pc / w, x = pc - y * w;
+      const float* ctr = w7lds + (y - ya + 3) * wp + (x + 3);
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float g = ctr[toff[k]];
+        a0 += w0[k] * g;
+        a1 += w1[k] * g;
+      }
+      a0 = group16_sum(a0);
+      a1 = group16_sum(a1);
+      if (!ok) continue;
+      const long pix = (long)b * hw + p;
+      const float4 g = *reinterpret_cast<const float4*>(dz + pix * TC + cq * 4);
+      const float4 v = *reinterpret_cast<const float4*>(u + pix * TC + cq * 4);
+      const float mm = m[pix];
+      const int a = argc[pix] - cq * 4;
+      const float dmean = a0 * (1.f / (float)TC);
+      float4 d;
+      d.x = mm * g.x + dmean + (a == 0 ? a1 : 0.f);
+      d.y = mm * g.y + dmean + (a == 1 ? a1 : 0.f);
+      d.z = mm * g.z + dmean + (a == 2 ? a1 : 0.f);
+      d.w = mm * g.w + dmean + (a == 3 ? a1 : 0.f);
+      acc.x += d.x * v.x;
+      acc.y += d.y * v.y;
+      acc.z += d.z * v.z;
+      acc.w += d.w * v.w;
+      *reinterpret_cast<float4*>(du + pix * TC + cq * 4) = make_float4(sc.x * d.x, sc.y * d.y, sc.z * d.z, sc.w * d.w);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 o = red[k * 16 + cq];
+      acc.x += o.x;
+      acc.y += o.y;
+      acc.z += o.z;
+      acc.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dsp + ((size_t)b * nblk + blockIdx.x) * TC + cq * 4) = acc;
+  }
+}
+
 // ---- B4: ds[b,c] = sum over block partials --------------------------------------------------------- //
 __global__ void tail_bwd_ds_kernel(const float* __restrict__ dsp, float* __restrict__ ds, int nblk) {
   const int b = blockIdx.x, c = threadIdx.x;
@@ -440,9 +541,20 @@ __global__ void tail_bwd_fix_kernel(float* __restrict__ du, const float* __restr
                                     const float* __restrict__ dmax, const int* __restrict__ arg, int hw, long npix,
                                     int pix_blocks, const float* __restrict__ pw1, const float* __restrict__ pw2,
                                     float* __restrict__ dfc1, float* __restrict__ dfc2, int n, int hidden, int accfc,
-                                    unsigned* __restrict__ du_pp = nullptr, int wd = 0, int guard = 0) {
+                                    unsigned* __restrict__ du_pp = nullptr, int wd = 0, int guard = 0, int red_blocks = 1 << 30,
+                                    const float* __restrict__ w7part = nullptr, float* __restrict__ dw7 = nullptr, int w7blk = 0,
+                                    int acc7 = 0) {
   // du_pp (round 5): the final du leaves as padded split-bf16 planes instead of fp32 (csrc/conv_wgrad_flat.hip: pixel row of 64 * 4 bytes,
   // per 8 channels 8 hi | 8 lo halves): the RAB's conv2 data gradient and weight gradient read it without a conversion pass
+  if ((int)blockIdx.x >= pix_blocks + red_blocks) {      // (round 6, behind tail_bwd_main2_kernel) slam_conv7_wgrad_reduce_kernel's sums: one wave per tap
+    const int t = ((int)blockIdx.x - pix_blocks - red_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= 98) return;
+    float a = 0.f;
+    for (int k = lane; k < w7blk; k += 64) a += w7part[(size_t)t * w7blk + k];
+    a = wave_sum(a);
+    if (lane == 0) dw7[t] = acc7 ? dw7[t] + a : a;
+    return;
+  }
   if ((int)blockIdx.x >= pix_blocks) {
     const int i = ((int)blockIdx.x - pix_blocks) * blockDim.x + threadIdx.x;
     const int per = hidden * TC;
@@ -1027,6 +1139,23 @@ int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, cons
   const size_t w7lds = ((size_t)W7_ROWS * w + 2 * (size_t)(W7_ROWS + 6) * (w + 6)) * sizeof(float);
   SRHIP_REQUIRE(w7lds <= 64 * 1024, "attn_tail_bwd: image too wide for the 7x7 weight-gradient strip");
   hipLaunchKernelGGL(tail_bwd_da_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, dz, u, s, m, da, hw, npix);
+  const int pix_blocks = (int)cdiv(npix, 16), red_blocks = (int)cdiv(2 * hidden * TC, 256);
+  SRHIP_REQUIRE(!du_pp || (((uintptr_t)du_pp) & 15) == 0, "attn_tail_bwd: du_pp must be 16-byte aligned");
+  // round 6: the 7x7 conv's data gradient inside the main pass (tail_bwd_main2_kernel) -- one launch less in the tail's serial chain;
+  // srhip_debug_set(7, 32): the round-5 sequence (da, slam_conv7_bwd, main, mlp, fix), kept for A/B runs
+  const int ngroups = (hw + 15) / 16, gpb = (int)cdiv(ngroups, TAIL_BLK);
+  const int tile_rows = (gpb * 16 + w - 1) / w + 1 + 6;
+  const size_t tile_lds = (size_t)tile_rows * (w + 6) * sizeof(float);
+  const size_t dyn = tile_lds > w7lds ? tile_lds : w7lds;
+  if (!(g_tail_dbg & 32) && dyn <= 60 * 1024) {
+    hipLaunchKernelGGL(tail_bwd_main2_kernel, dim3(TAIL_BLK + strips, n), dim3(256), dyn, st, dz, u, s, m, da, w7,
+                       reinterpret_cast<const float2*>(pooled), argc, du, dsp, w7part, h, w, TAIL_BLK, strips, gpb, tile_rows);
+    hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
+    hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(pix_blocks + red_blocks + 25), dim3(256), 0, st, du, davg, dmax, argmax_hw, hw, npix, pix_blocks,
+                       pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc, static_cast<unsigned*>(du_pp), w, srhip_pp_guard(w), red_blocks,
+                       w7part, dw7, w7blk, accumulate_dw7);
+    return check_launch("attn_tail_bwd");
+  }
   const int nd7 = (int)cdiv(npix, 256);
   if (g_tail_dbg & 16) {                              // srhip_debug_set(7, 16): the two launches of rounds 2-3 (A/B)
     hipLaunchKernelGGL(slam_conv7_dgrad_kernel, dim3(nd7), dim3(256), 0, st, da, w7, dpooled, h, w, npix);
@@ -1038,8 +1167,6 @@ int srhip_attn_tail_bwd_pp(const float* dz, const float* u, const float* s, cons
   hipLaunchKernelGGL(tail_bwd_main_kernel<true>, dim3(TAIL_BLK + 1, n), dim3(256), 0, st, dz, u, s, m, dpooled, argc, du, dsp, hw,
                      w7part, dw7, w7blk, accumulate_dw7);
   hipLaunchKernelGGL(clam_mlp_bwd_kernel, dim3(n), dim3(TC), 0, st, dsp, avg, mx, s, fc1, fc2, davg, dmax, pw1, pw2, hidden, TAIL_BLK);
-  const int pix_blocks = (int)cdiv(npix, 16), red_blocks = (int)cdiv(2 * hidden * TC, 256);
-  SRHIP_REQUIRE(!du_pp || (((uintptr_t)du_pp) & 15) == 0, "attn_tail_bwd: du_pp must be 16-byte aligned");
   hipLaunchKernelGGL(tail_bwd_fix_kernel, dim3(pix_blocks + red_blocks), dim3(256), 0, st, du, davg, dmax, argmax_hw, hw, npix, pix_blocks,
                      pw1, pw2, dfc1, dfc2, n, hidden, accumulate_dfc, static_cast<unsigned*>(du_pp), w, srhip_pp_guard(w));
   return check_launch("attn_tail_bwd");

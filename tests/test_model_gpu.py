@@ -311,7 +311,8 @@ def test_near_tie_inputs_keep_the_losses_and_all_but_a_few_gradient_entries():
     (3.7e-6 for the first candidate: inside the ~5e-6 of either conv arithmetic) -- and asserts what must survive a flipped branch
     (sradsgan.py:470-508 under :829-892): the six loss scalars of both iterations stay within 1e-3 (the forward is continuous at the
     kink), the generator's gradients stay within the usual bar (the flip sits behind weight_gan = 1e-3), and the discriminator's
-    gradients differ only LOCALLY: every tensor keeps >= 90 % of its elements within 2e-2, the network >= 99.5 %."""
+    gradients differ only LOCALLY: every tensor keeps >= 99 % of its elements within 2e-2, the network >= 99.9 % (measured: 99.94 % /
+    99.991 %, while the max-norm score of the flipped layer's weight gradient reads 5.9e-2)."""
     from sradsgan_amd.train_step import TrainStep
     from tests.parity_util import closest_deep_preactivation, grad_fraction
     scale, lr_side, batch = 2, 16, 2
@@ -341,7 +342,7 @@ def test_near_tie_inputs_keep_the_losses_and_all_but_a_few_gradient_entries():
         assert worst < TOL, (it, worst)
         if it == 0:                                      # identical weights on both sides: the clean comparison
             assert sg < 5e-3, (sg, kg)
-            assert fd >= 0.90 and fall >= 0.995, (fd, fk, fall)
+            assert fd >= 0.99 and fall >= 0.999, (fd, fk, fall)
 
 
 def test_train_two_iterations_full_size(golden):
@@ -791,6 +792,40 @@ def test_group_tail_hands_its_output_over_as_planes_bit_identical():
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize('shape', [(2, 23, 37), (3, 27, 27), (1, 9, 20), (8, 54, 54), (1, 108, 108), (2, 5, 70)])
+def test_tail_backward_with_the_7x7_data_gradient_inside_the_main_pass(shape):
+    """Round 6: tail_bwd_main2_kernel computes dpooled = conv_transpose7x7(da, w7) itself from an LDS tile of da (16 lanes of a pixel
+    split the 49 taps) instead of reading what slam_conv7_bwd_kernel wrote -- one launch less in every tail's serial chain (autograd of
+    sradsgan.py:141-151 inside :254-274).  Against the round-5 launch sequence (srhip_debug_set(7, 32)), which the oracle tests pinned:
+    output, skip gradient and the 7x7 weight gradient (same strips, same reduce order) bit-identical, every other gradient within 2e-5 of
+    its largest magnitude (another summation order of 49 products).  Shapes: images narrower / wider than a block's pixel range, partial
+    last groups, one group per block and sixteen."""
+    from sradsgan_amd import _hip, ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + 6)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    u0, skip0, dy = (cl(torch.randn(n, 64, h, w, generator=g)) for _ in range(3))
+    par0 = [(torch.randn(4, 64, 1, 1, generator=g) * 0.2), (torch.randn(64, 4, 1, 1, generator=g) * 0.2), (torch.randn(1, 2, 7, 7, generator=g) * 0.1),
+            (torch.randn(64, 64, 1, 1, generator=g) * 0.1), (torch.randn(64, generator=g) * 0.1)]
+    res = []
+    for old_sequence in (False, True):
+        _hip.lib().srhip_debug_set(7, 32 if old_sequence else 0)
+        try:
+            u, skip = u0.clone().requires_grad_(True), skip0.clone().requires_grad_(True)
+            par = [p.clone().to(DEV).requires_grad_(True) for p in par0]
+            out = ops.attention_tail(u, skip, *par)
+            out.backward(dy)
+            torch.cuda.synchronize()
+            res.append([out.detach().clone(), u.grad.clone(), skip.grad.clone()] + [p.grad.clone() for p in par])
+        finally:
+            _hip.lib().srhip_debug_set(7, 0)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][5], res[1][5]), 'dw7'
+    for a, b, name in zip(res[0][1:], res[1][1:], ['du', 'dskip', 'dfc1', 'dfc2', 'dw7', 'dwc', 'dbc']):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+        assert err < 2e-5, (name, err)
 
 
 def test_compact_record_shortcuts_leave_the_training_step_bit_identical():
