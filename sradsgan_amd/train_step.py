@@ -115,6 +115,9 @@ class TrainStep:
         self._parts_armed = False
         self._parts_sent = set()
         self._main = None
+        if grad_sync is not None and grad_sync.active and dev.type == 'cuda':
+            grad_sync.init_rccl(dev)                     # the communicator's rendezvous happens HERE, on the calling thread -- not inside the
+                                                         # first backward, where the first part's hand-over runs on autograd's device thread
         for k, grp in self._part_groups:
             grp.register_forward_hook(self._make_part_hook(k))
         for p in self.F.parameters():

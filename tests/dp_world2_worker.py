@@ -35,6 +35,7 @@ def main():
     step(*batch(0))
     torch.cuda.synchronize()
     assert sync.rccl_ranks() == world
+    assert [p for t, p, _, _ in sync.parts if t == 'G'] == [0, 1, 2, 3], sync.parts      # 2 groups: group 1 + up-sampler, group 0, head, MSB + tail conv
     got = [step.arena_G.flat_g.clone(), step.arena_D.flat_g.clone()]
     (g2, d2, f2), _ = build_pair(2, 2, 4, dev)                   # the same replica without the exchange: local gradients
     plain = TrainStep(g2, d2, f2, lr=0.0, clip_value=0.0)
