@@ -134,7 +134,8 @@ def _check_first_iteration_gradients(label, grads, ograds, scale, lr_side, batch
     ed, ekd, ed_all = grad_fraction((grads[1],), (d64,), 2e-2)
     print('%s split-bf16 vs fp64, share of elements within G 5e-3 / D 2e-2: G worst tensor %.4f (%s), all %.5f; D worst tensor %.4f (%s), all %.5f'
           % (label, eg, ekg, eg_all, ed, ekd, ed_all))
-    assert eg_all >= 0.999 and ed_all >= 0.999, ('split-bf16 element shares', eg_all, ed_all)
+    # measured: x8 G 2 of 64 entries of one bias vector out (share of ALL elements 0.999999+), D 4 of 64 (model.3.bias); x9 1 / 2 entries
+    assert eg_all >= 0.9999 and ed_all >= 0.9999, ('split-bf16 element shares', eg_all, ed_all)
 
 
 @pytest.mark.parametrize('scale,lr_side', [(2, 108), (3, 72), (8, 27), (9, 24)])
