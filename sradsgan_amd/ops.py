@@ -788,6 +788,8 @@ if os.environ.get('SRHIP_PERS_GRID'):                          # experiment: blo
     _hip.lib().srhip_debug_set(5, int(os.environ['SRHIP_PERS_GRID']))
 if os.environ.get('SRHIP_FLAT_BLOCKS'):                        # experiment: blocks of the 8-wave weight-gradient kernel (default: one per CU)
     _hip.lib().srhip_debug_set(12, int(os.environ['SRHIP_FLAT_BLOCKS']))
+if os.environ.get('SRHIP_FLAT_F32_K8'):                       # experiment: 0 = a weight gradient with one fp32 operand takes the 4-wave flat kernel
+    _hip.lib().srhip_debug_set(14, int(os.environ['SRHIP_FLAT_F32_K8']))
 if os.environ.get('SRHIP_TAIL_DBG'):                           # A/B knob: bit 32 = the round-5 launch sequence of the tail's backward (7x7 data gradient as its own launch)
     _hip.lib().srhip_debug_set(7, int(os.environ['SRHIP_TAIL_DBG']))
 _X_PP = os.environ.get('SRHIP_X_PP', '1') == '1'                # A/B knob: 0 = a RAB's input never arrives as planes (conversion pass for its weight gradient)
