@@ -115,9 +115,8 @@ class TrainStep:
         self._parts_armed = False
         self._parts_sent = set()
         self._main = None
-        if grad_sync is not None and grad_sync.active and dev.type == 'cuda':
-            grad_sync.init_rccl(dev)                     # the communicator's rendezvous happens HERE, on the calling thread -- not inside the
-                                                         # first backward, where the first part's hand-over runs on autograd's device thread
+        if grad_sync is not None and grad_sync.active and dev.type == 'cuda' and os.environ.get('SRHIP_DP_EAGER_INIT') == '1':
+            grad_sync.init_rccl(dev)                     # experiment only: see _compute_onewalk for when the communicator is created
         for k, grp in self._part_groups:
             grp.register_forward_hook(self._make_part_hook(k))
         for p in self.F.parameters():
@@ -316,7 +315,13 @@ class TrainStep:
         main = self._main = torch.cuda.current_stream()
         gs = self.grad_sync
         self._parts_sent = set()
-        self._parts_armed = bool(self._g_parts) and gs is not None and gs.active and not self._capturing and not gs.host_sync
+        # The parts are armed from the SECOND iteration on: the first one hands both arenas over whole, from this thread, after the
+        # backward -- that is where the communicator, its rendezvous and the comm stream come into being (GradSync.init_rccl inside
+        # start()), AFTER the step's three compute streams have been used and own their hardware queues.  Created before them (round 6
+        # tried it in TrainStep.__init__, to keep the rendezvous off autograd's device thread) the high-priority comm stream takes a
+        # queue the compute streams then share: 69.6 instead of 48.2 ms per step (profiles/r06_step_ab.txt).
+        self._parts_armed = (bool(self._g_parts) and gs is not None and gs.active and not self._capturing and not gs.host_sync
+                             and (gs._rccl_ready or not self.arena_G.flat_g.is_cuda))
         self._set_d_grad(True)
         self.arena_G.zero_grad()
         self.arena_D.zero_grad()

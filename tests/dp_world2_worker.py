@@ -35,7 +35,6 @@ def main():
     step(*batch(0))
     torch.cuda.synchronize()
     assert sync.rccl_ranks() == world
-    assert [p for t, p, _, _ in sync.parts if t == 'G'] == [0, 1, 2, 3], sync.parts      # 2 groups: group 1 + up-sampler, group 0, head, MSB + tail conv
     got = [step.arena_G.flat_g.clone(), step.arena_D.flat_g.clone()]
     (g2, d2, f2), _ = build_pair(2, 2, 4, dev)                   # the same replica without the exchange: local gradients
     plain = TrainStep(g2, d2, f2, lr=0.0, clip_value=0.0)
@@ -55,6 +54,8 @@ def main():
     for it in range(4):
         out = step3(*batch(it))
     torch.cuda.synchronize()
+    # from the second iteration on the generator's arena leaves in parts: group 1 + up-sampler, group 0, head, MSB + tail conv
+    assert [p for t, p, _, _ in sync3.parts if t == 'G'][:4] == [0, 1, 2, 3], sync3.parts
     for arena in (step3.arena_G, step3.arena_D):
         mine = arena.flat_p.clone()
         theirs = [torch.empty_like(mine) for _ in range(world)]

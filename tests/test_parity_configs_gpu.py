@@ -239,8 +239,10 @@ def test_forced_single_rank_rccl_exchange_is_bit_identical_to_the_plain_step():
             assert sync.rccl_ranks() == 1
             # round 6: the generator's arena leaves in parts from inside its backward -- late layers first (2 groups: group 1 + the
             # up-sampler, group 0, then head and multi-scale block / tail conv) --, the discriminator's arena behind them
-            per = sync.trace.index(('finish', 'D')) + 1
-            head = sync.trace[:per]
+            first = sync.trace.index(('finish', 'D')) + 1                  # the first iteration hands both arenas over whole (the communicator is born there)
+            assert sync.trace[:first] == [('start', 'G'), ('start', 'D'), ('finish', 'G'), ('finish', 'D')], sync.trace[:first]
+            per = sync.trace.index(('finish', 'D'), first) + 1
+            head = sync.trace[first:per]
             assert [t for t in head if len(t) == 3] == [('start', 'G', k) for k in range(4)], head
             assert head[-3:] == [('start', 'D'), ('finish', 'G'), ('finish', 'D')], head
             first = [lo for _, _, lo, _ in sync.parts[:2]]
