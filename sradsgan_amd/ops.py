@@ -38,6 +38,7 @@ class _State:
     carry_expect = None             # token -> number of consumers that committed to stash at forward time
     carry_token = 0
     wgrad_seq = 0                   # weight-gradient requests so far (the age of a pending launch, _age_pending)
+    ready_pairs = None              # complete flat-kernel launches waiting for their slot behind a conv1 data gradient (_WGRAD_SLOTS)
 
 
 _state = _State()
@@ -84,9 +85,9 @@ def direct_param_grads(side_stream=None, group=1):
     them: one wgrad launch per conv instead of wgrad + one `grad += new` launch per parameter
     (~600 tiny launches per step).  Only valid when every such parameter already owns a dense .grad
     and nobody asks autograd for these gradients explicitly (TrainStep guarantees both)."""
-    prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held)
+    prev = (_state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held, _state.ready_pairs)
     _state.direct_grads, _state.wgrad_stream = True, side_stream
-    _state.wgrad_group, _state.pending, _state.held = (group if side_stream is not None else 1), {}, []
+    _state.wgrad_group, _state.pending, _state.held, _state.ready_pairs = (group if side_stream is not None else 1), {}, [], []
     try:
         yield
         flush_pending_wgrads()
@@ -94,7 +95,7 @@ def direct_param_grads(side_stream=None, group=1):
             raise RuntimeError('direct_param_grads: %d grouped weight gradient(s) still waiting for a partner after the flush'
                                % len(_state.pending))
     finally:
-        _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held = prev
+        _state.direct_grads, _state.wgrad_stream, _state.wgrad_group, _state.pending, _state.held, _state.ready_pairs = prev
 
 
 _HOLD = int(os.environ.get('SRHIP_HOLD', '1'))     # 1: passed-through gradients (default); 2: every side-stream operand; 0: off (test knob)
@@ -874,7 +875,10 @@ def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
         q = _state.pending.setdefault(key, [])
         q.append(item + (_stream().value, _state.wgrad_seq))
         if len(q) >= 2:
-            _flush_key(key)
+            if _WGRAD_SLOTS and _state.ready_pairs is not None and not _state.capturing:
+                _state.ready_pairs.append(_state.pending.pop(key))      # complete: goes out at the next slot (release_ready_pair)
+            else:
+                _flush_key(key)
         return True
     _fork_side(side)
     _launch_wgrad_pp([item], side)
@@ -932,9 +936,38 @@ def _age_pending():
         _flush_key(key)
 
 
+_WGRAD_SLOTS = os.environ.get('SRHIP_WGRAD_SLOTS', '1') == '1'
+
+
+def _launch_ready(items):
+    side = _state.wgrad_stream
+    _fork_side(side, [it[5] for it in items])
+    _launch_wgrad_pp([it[:5] for it in items], side)
+
+
+def release_ready_pair(n=1):
+    """Round 6: WHEN a complete pair of RAB weight gradients starts.  The 8-wave flat kernel holds one block on every CU for ~150 us
+    (2 x 170 of the 512 registers per SIMD lane) and leaves room for ONE block of a main-stream conv beside it.  The 128-wide conv
+    kernels live with that (12 MFMAs per barrier and wave: 87 us in the step against 79 alone); the 64-wide one -- conv1's data gradient,
+    256 -> 64, 6 MFMAs per barrier -- does not: 149 us in the step against 77 alone, 36 times per step on the main stream's chain
+    (profiles/r06_step_eager_kernel_stats.txt).  And the round-5 request order put the two exactly on top of each other: conv2's
+    weight gradient was requested between conv2's and conv1's data gradient, so a pair that completed there started the moment
+    conv1's data gradient did.  Now complete pairs wait in _state.ready_pairs and ONE goes out right after every conv1 data gradient
+    has been enqueued (_RabBlock._backward_planes): it runs beside the next block's attention tail (streaming passes) and conv2 data
+    gradient (128-wide) -- ~210 us, room for one pair -- and is mostly done when the next conv1 data gradient starts.  Same kernels,
+    same accumulation order per parameter: bit-identical."""
+    q = _state.ready_pairs
+    while q and n > 0:
+        _launch_ready(q.pop(0))
+        n -= 1
+
+
 def flush_pending_wgrads():
-    """Launches every weight gradient that is still waiting for a partner of its shape.  Called wherever something is about to
-    order itself behind "all weight gradients so far": the exchange, the joins of the step, the end of direct_param_grads()."""
+    """Launches every weight gradient that is still waiting for a partner of its shape (and every complete pair that is waiting for
+    its slot).  Called wherever something is about to order itself behind "all weight gradients so far": the exchange, the joins of
+    the step, the end of direct_param_grads()."""
+    if _state.ready_pairs:
+        release_ready_pair(len(_state.ready_pairs))
     if _state.pending:
         for key in list(_state.pending):
             _flush_key(key)
@@ -1512,12 +1545,17 @@ class _RabBlock(Function):
         dw2 = db2 = dw1 = db1 = None
         main = torch.cuda.current_stream()
         t_done = dt_done = False
+        slots = _WGRAD_SLOTS and _state.ready_pairs is not None
+        if slots:                                         # conv1's data gradient FIRST, then one waiting pair of weight gradients (release_ready_pair)
+            dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None
+            release_ready_pair(1)
         if not skip:
             t_done = wgrad_pp_for_params(w2, b2, t_pp, du_pp if du_pp is not None else du, ctx.has_b[1],
                                          release=(t_pp,) if du_pp is None else (t_pp, du_pp))
             if not t_done:                                # autograd wants the gradients returned: the fp32 path on converted operands
                 dw2, db2 = wgrad_for_params(w2, b2, pp_to_f32(t_pp), du if du is not None else pp_to_f32(du_pp), 1, 1, ctx.has_b[1])
-        dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None   # + skip gradient (+ the input's stashed gradients)
+        if not slots:
+            dx = conv2d_dgrad_pp_raw(dt_pp, w1, residual=g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None   # + skip gradient (+ the input's stashed gradients)
         if not skip:
             dt_done = wgrad_pp_for_params(w1, b1, x_pp if x_pp is not None else x, dt_pp, ctx.has_b[0],
                                           release=(dt_pp,) if x_pp is None else (dt_pp, x_pp))
@@ -1531,6 +1569,8 @@ class _RabBlock(Function):
             plane_pool.put(dt_pp, (main,))
             if x_pp is not None:
                 plane_pool.put(x_pp, (main,))
+        if slots and x_pp is None:                        # the trunk's first block = the backward's last: no further slot will come
+            release_ready_pair(len(_state.ready_pairs))
         return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None
 
 

@@ -842,7 +842,7 @@ def test_compact_record_shortcuts_leave_the_training_step_bit_identical():
     lr = O.det_fill('rec.lr', (B, 3, side, side), 0.5, 0.5).to(DEV)
     hr = O.det_fill('rec.hr', (B, 3, side * scale, side * scale), 0.5, 0.5).to(DEV)
     al = O.det_fill('rec.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
-    knobs = ('_PP_SIGNS', '_POOL_IDX', '_LRELU_BITS', '_BN_BWD_X', '_BN_FOLD')
+    knobs = ('_PP_SIGNS', '_POOL_IDX', '_LRELU_BITS', '_BN_BWD_X', '_BN_FOLD', '_WGRAD_SLOTS')     # (round 6: + WHEN complete weight-gradient pairs start, ops.release_ready_pair)
     assert all(getattr(ops, k) for k in knobs)
 
     def run(on):
