@@ -936,7 +936,7 @@ def _age_pending():
         _flush_key(key)
 
 
-_WGRAD_SLOTS = os.environ.get('SRHIP_WGRAD_SLOTS', '1') == '1'
+_WGRAD_SLOTS = os.environ.get('SRHIP_WGRAD_SLOTS', '0') == '1'     # experiment, OFF: see release_ready_pair (kernel-level effect as predicted, step unchanged)
 
 
 def _launch_ready(items):
@@ -955,7 +955,11 @@ def release_ready_pair(n=1):
     conv1's data gradient did.  Now complete pairs wait in _state.ready_pairs and ONE goes out right after every conv1 data gradient
     has been enqueued (_RabBlock._backward_planes): it runs beside the next block's attention tail (streaming passes) and conv2 data
     gradient (128-wide) -- ~210 us, room for one pair -- and is mostly done when the next conv1 data gradient starts.  Same kernels,
-    same accumulation order per parameter: bit-identical."""
+    same accumulation order per parameter: bit-identical.
+    MEASURED (profiles/r06_step_ab.txt): conv1's data gradient 147.7 -> 91.6 us in the step, exactly as intended -- and the step does not
+    move (668.8 / 672.3 / 671.1 against 669.5 / 672.1 / 671.0 img/s): the tail's 1x1 data gradient (39 -> 48 us), the split-K reduces
+    (23 -> 31) and the 1x1 weight gradients (35 -> 40) take up what it gives back.  During the backward the chip's throughput is the limit,
+    not any kernel's place in a queue.  Kept as an option (SRHIP_WGRAD_SLOTS=1), off by default."""
     q = _state.ready_pairs
     while q and n > 0:
         _launch_ready(q.pop(0))

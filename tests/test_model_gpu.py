@@ -828,6 +828,37 @@ def test_tail_backward_with_the_7x7_data_gradient_inside_the_main_pass(shape):
         assert err < 2e-5, (name, err)
 
 
+def test_weight_gradient_slots_leave_the_training_step_bit_identical():
+    """Round 6 experiment (ops.release_ready_pair, SRHIP_WGRAD_SLOTS): complete pairs of RAB weight gradients start in slots behind
+    conv1's data gradient instead of the moment they complete.  Same kernels, same accumulation per parameter: one full iteration
+    (sradsgan.py:818-892) is bit-identical with the option on and off (3 groups x 2 RABs: pairs complete, wait and are flushed)."""
+    from sradsgan_amd import ops
+    from sradsgan_amd.train_step import TrainStep
+    if ops.get_conv_math() != 'bf16x3':
+        pytest.skip('the flat weight gradient is a split-bf16 path')
+    B, side, scale = 4, 24, 4
+    lr = O.det_fill('slots.lr', (B, 3, side, side), 0.5, 0.5).to(DEV)
+    hr = O.det_fill('slots.hr', (B, 3, side * scale, side * scale), 0.5, 0.5).to(DEV)
+    al = O.det_fill('slots.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
+
+    def run(on):
+        old, ops._WGRAD_SLOTS = ops._WGRAD_SLOTS, on
+        try:
+            (hg, hd, hf), _ = build_pair(3, 2, scale, DEV)
+            step = TrainStep(hg, hd, hf)
+            out = step(lr, hr, al)
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().clone() for p in list(hg.parameters()) + list(hd.parameters())]
+            return torch.stack([out[k].double() for k in ('loss_G', 'loss_D', 'pixel', 'content', 'loss_gan', 'gp')]).cpu(), grads
+        finally:
+            ops._WGRAD_SLOTS = old
+
+    s1, g1 = run(True)
+    s0, g0 = run(False)
+    assert torch.isfinite(s1).all() and torch.equal(s1, s0)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
 def test_compact_record_shortcuts_leave_the_training_step_bit_identical():
     """Round 5 replaced several re-reads of large tensors by compact records or by the producing pass itself: the RAB's LeakyReLU mask
     as sign words (ops._PP_SIGNS), VGG's max-pool arg-max records (_POOL_IDX), the head activation's sign bits in the penalty's double
@@ -842,7 +873,7 @@ def test_compact_record_shortcuts_leave_the_training_step_bit_identical():
     lr = O.det_fill('rec.lr', (B, 3, side, side), 0.5, 0.5).to(DEV)
     hr = O.det_fill('rec.hr', (B, 3, side * scale, side * scale), 0.5, 0.5).to(DEV)
     al = O.det_fill('rec.alpha', (B, 1, 1, 1), 0.5, 0.5).to(DEV)
-    knobs = ('_PP_SIGNS', '_POOL_IDX', '_LRELU_BITS', '_BN_BWD_X', '_BN_FOLD', '_WGRAD_SLOTS')     # (round 6: + WHEN complete weight-gradient pairs start, ops.release_ready_pair)
+    knobs = ('_PP_SIGNS', '_POOL_IDX', '_LRELU_BITS', '_BN_BWD_X', '_BN_FOLD')
     assert all(getattr(ops, k) for k in knobs)
 
     def run(on):
