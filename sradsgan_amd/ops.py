@@ -874,7 +874,7 @@ def wgrad_pp_for_params(w, b, x, dy, want_b, release=()):
         key = ('pp', tuple(x.shape), w.shape[0], gb is not None, isinstance(x, PP), isinstance(dy, PP))   # one launch = one operand format
         q = _state.pending.setdefault(key, [])
         q.append(item + (_stream().value, _state.wgrad_seq))
-        if len(q) >= 2:
+        if len(q) >= _PP_GROUP:
             if _WGRAD_SLOTS and _state.ready_pairs is not None and not _state.capturing:
                 _state.ready_pairs.append(_state.pending.pop(key))      # complete: goes out at the next slot (release_ready_pair)
             else:
@@ -936,6 +936,7 @@ def _age_pending():
         _flush_key(key)
 
 
+_PP_GROUP = max(2, min(4, int(os.environ.get('SRHIP_PP_GROUP', '2'))))     # RAB weight gradients of one shape per flat-kernel launch (2: pairs; experiment: 3, 4)
 _WGRAD_SLOTS = os.environ.get('SRHIP_WGRAD_SLOTS', '0') == '1'     # experiment, OFF: see release_ready_pair (kernel-level effect as predicted, step unchanged)
 
 
