@@ -921,7 +921,7 @@ def _flush_key(key):
         _hold_for_side(side, it[1])
 
 
-_WGRAD_MAX_AGE = int(os.environ.get('SRHIP_WGRAD_MAX_AGE', '8'))    # weight-gradient calls a launch may wait for a partner (0: until the next flush point)
+_WGRAD_MAX_AGE = int(os.environ.get('SRHIP_WGRAD_MAX_AGE', '14'))    # weight-gradient calls a launch may wait for a partner (0: until the next flush point)
 
 
 def _age_pending():
@@ -936,7 +936,10 @@ def _age_pending():
         _flush_key(key)
 
 
-_PP_GROUP = max(2, min(4, int(os.environ.get('SRHIP_PP_GROUP', '2'))))     # RAB weight gradients of one shape per flat-kernel launch (2: pairs; experiment: 3, 4)
+# RAB weight gradients of one shape per flat-kernel launch.  Round 6: 3 -- a ResGroup's three RABs -- instead of pairs: the launch keeps one
+# block per CU, so every convolution gets a third instead of half of the split-K splits (28 instead of 42): a third fewer partial tiles written and
+# reduced, and the launches line up with the group boundaries the exchange's parts are cut at.  +0.5 % same-box (profiles/r06_step_ab.txt; 4: the same)
+_PP_GROUP = max(2, min(4, int(os.environ.get('SRHIP_PP_GROUP', '3'))))
 _WGRAD_SLOTS = os.environ.get('SRHIP_WGRAD_SLOTS', '0') == '1'     # experiment, OFF: see release_ready_pair (kernel-level effect as predicted, step unchanged)
 
 

@@ -85,7 +85,7 @@ def test_flat_wgrad_against_fp64(case):
 @pytest.mark.parametrize('case', [(2, 64, 23, 37, 128, 2, 'dy'), (3, 128, 19, 40, 64, 2, 'x'), (32, 64, 54, 54, 256, 2, 'dy'), (32, 256, 54, 54, 64, 2, 'x'),
                                   (4, 64, 27, 27, 256, 4, 'dy'), (2, 256, 24, 24, 64, 3, 'x'), (32, 64, 54, 54, 256, 2, 'both'),
                                   (32, 256, 54, 54, 64, 2, 'both'), (4, 64, 27, 27, 256, 4, 'both'), (2, 256, 24, 24, 64, 3, 'both'),
-                                  (3, 64, 11, 9, 576, 2, 'both')])
+                                  (3, 64, 11, 9, 576, 2, 'both'), (32, 64, 54, 54, 256, 3, 'both'), (32, 256, 54, 54, 64, 3, 'both')])     # (the last two: the step's launches since round 6)
 def test_grouped_flat_wgrad_matches_the_single_launches(case):
     """nprob weight gradients of one shape behind one launch (every problem with nsplit / nprob splits): the same products summed
     over fewer, longer splits -- equal to the single launches up to the summation order, with and without a bias gradient."""
