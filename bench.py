@@ -277,7 +277,12 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
     kw_label = (kw + ' x%d convolutions per launch + %d reduces' % (group, group)) if group > 1 else (kw + ' + reduce')
     wgrad_extra = {}
     wgrad_calls = 1
-    if math == 'bf16x3' and group == 2 and ops.rab_planes_ok(x, w, torch.empty(64, 256, 3, 3, device='meta')):
+    if math == 'bf16x3' and group >= 2 and ops.rab_planes_ok(x, w, torch.empty(64, 256, 3, 3, device='meta')):
+        group = ops._PP_GROUP                              # round 6: the step launches a ResGroup's THREE RABs per flat-kernel launch (ops._PP_GROUP)
+        gw = [torch.zeros(256, 64, 3, 3, device=device) for _ in range(group)]
+        gb = [torch.zeros(256, device=device) for _ in range(group)]
+        items = [((x, x2)[i % 2], (dy, dy2)[i % 2], gw[i], gb[i], 1, 1) for i in range(group)]
+        nlaunch = 36 // group                              # launches of this shape per step (36 RABs)
         # Round 5: inside the RAB the step keeps dy (the 256-channel gradient, written by conv2's dgrad epilogue) as padded
         # split-bf16 planes and launches the pair on the flat 8-wave kernel (csrc/conv_wgrad_flat.hip); the 64-channel operand x is
         # converted by a small pass on the weight-gradient stream.  Timed here: exactly that -- two pp_from_f32 passes of x + the
@@ -289,9 +294,9 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
         # weight-gradient stream: one pass per 18 pair launches, which `frac` includes (`conversion_pass_ms`, `pair_launch_alone_*` without it).
         sets = []
         for k in range(3):
-            xs_ = (x, x2) if k == 0 else (torch.randn_like(x), torch.randn_like(x))
-            dys_ = (dy, dy2) if k == 0 else (torch.randn_like(dy), torch.randn_like(dy))
-            sets.append([(ops.pp_from_f32(xs_[i]), ops.pp_from_f32(dys_[i]), gw[i], gb[i]) for i in range(2)])
+            xs_ = [x, x2] + [torch.randn_like(x) for _ in range(group - 2)] if k == 0 else [torch.randn_like(x) for _ in range(group)]
+            dys_ = [dy, dy2] + [torch.randn_like(dy) for _ in range(group - 2)] if k == 0 else [torch.randn_like(dy) for _ in range(group)]
+            sets.append([(ops.pp_from_f32(xs_[i]), ops.pp_from_f32(dys_[i]), gw[i], gb[i]) for i in range(group)])
         ppx_scratch = ops.pp_empty(batch, 64, LR_SIDE, LR_SIDE, device)
         rot = [0]
 
@@ -299,17 +304,17 @@ def time_dominant_kernel(device, batch, sustained=True, with_single=True):
             rot[0] = (rot[0] + 1) % 3
             ops.conv2d_wgrad_pp_raw(sets[rot[0]])
 
-        def wgrad_pp():                                     # 18 pair launches + one conversion pass = the 36 conv1 weight gradients of one step
-            for _ in range(18):
+        def wgrad_pp():                                     # nlaunch grouped launches + one conversion pass = the 36 conv1 weight gradients of one step
+            for _ in range(nlaunch):
                 pair_alone()
             ops.pp_from_f32(x, out=ppx_scratch)
         wgrad_fn = wgrad_pp
-        wgrad_calls = 18                                    # pair launches per call of wgrad_fn
+        wgrad_calls = nlaunch                               # grouped launches per call of wgrad_fn
         pitems = sets[0]
-        kw_label = ('wgrad_flat8_kernel<dy planes 256 ch, x planes 64 ch> x2 convolutions per launch + reduce, operands cold (three sets in rotation), '
-                    '+ 1/18 pp_from_f32 pass of x per launch (the first RAB of the trunk)')
+        kw_label = ('wgrad_flat8_kernel<dy planes 256 ch, x planes 64 ch> x%d convolutions per launch + reduce, operands cold (three sets in rotation), '
+                    '+ 1/%d pp_from_f32 pass of x per launch (the first RAB of the trunk)' % (group, nlaunch))
         if with_single:                                   # (not under the profiler: its per-kernel averages and byte counters then belong to the launch the step runs)
-            wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(pair_alone, 300), 4)
+            wgrad_extra['pair_launch_alone_ms'] = round(_time_launches(pair_alone, 300), 4)       # (key names of round 5: "pair" = the grouped launch, `convolutions_per_launch` convolutions)
             wgrad_extra['conversion_pass_ms'] = round(_time_launches(lambda: ops.pp_from_f32(x, out=ppx_scratch), 200), 4)
             wgrad_extra['rowtap_pair_launch_ms'] = round(_time_launches(lambda: ops.conv2d_wgrad_multi_raw(items), 200), 4)
         single_wgrad = lambda: ops.conv2d_wgrad_pp_raw(pitems[:1])

@@ -135,7 +135,8 @@ class RAB(nn.Module, _AttentionTail):
         if self._fusable(x):
             return ops.rab_block(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
                                  self.ca.fc1.weight, self.ca.fc2.weight, self.sa.conv1.weight, self.conv.weight,
-                                 self.conv.bias, emit_pp=getattr(self, '_next_is_rab', False))
+                                 self.conv.bias, emit_pp=getattr(self, '_next_is_rab', False),
+                                 group_first=getattr(self, '_group_first', False))
         out = self.conv2(self.conv1(x, act_slope=0.2))
         return self._tail(out, x)
 
@@ -152,6 +153,8 @@ class ResGroup(nn.Module, _AttentionTail):
                   la_mode=bla_mode, pool_mode=pool_mode, addconv=addconv) for _ in range(n_blocks)])
         for blk, nxt in zip(list(self.RG)[:-1], list(self.RG)[1:]):      # a RAB feeding a RAB may hand its output over in both forms (ops.rab_block)
             blk._next_is_rab = isinstance(blk, RAB) and isinstance(nxt, RAB)
+        if n_blocks and isinstance(self.RG[0], RAB):
+            self.RG[0]._group_first = True       # its backward is the group's last: the group's weight gradients leave as ONE launch (ops.rab_block)
         self._build_tail(rla_mode, pool_mode, nc, addconv)
 
     def forward(self, x):

@@ -970,6 +970,16 @@ def release_ready_pair(n=1):
         n -= 1
 
 
+def flush_pending_pp():
+    """The RAB weight gradients of the flat kernel that are still waiting for partners go out now (end of a ResGroup's backward)."""
+    if _state.pending:
+        for key in [k for k in _state.pending if k[0] == 'pp']:
+            if _WGRAD_SLOTS and _state.ready_pairs is not None and not _state.capturing:
+                _state.ready_pairs.append(_state.pending.pop(key))
+            else:
+                _flush_key(key)
+
+
 def flush_pending_wgrads():
     """Launches every weight gradient that is still waiting for a partner of its shape (and every complete pair that is waiting for
     its slot).  Called wherever something is about to order itself behind "all weight gradients so far": the exchange, the joins of
@@ -1472,12 +1482,13 @@ class _RabBlock(Function):
     gradient-accumulation adds, 3 saved activations (x, t, u) instead of ~12."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp=None, emit_pp=False, carry=None):
+    def forward(ctx, x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp=None, emit_pp=False, carry=None, group_first=False):
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
         ctx.carry = carry              # token under which the input's other consumers stash their gradients (carry_open)
         ctx.t_pp = ctx.x_pp = ctx.signs = None
         ctx.planes = False
+        ctx.group_first = bool(group_first)   # the first block of a ResGroup: its backward closes the group's weight-gradient launch
         _state.last_out_pp = None
         if rab_planes_ok(x, w1, w2):
             # round 5: t stays in padded split-bf16 planes between the block's own kernels (conv1's epilogue writes them, conv2 reads
@@ -1530,7 +1541,7 @@ class _RabBlock(Function):
         dx = conv2d_dgrad_raw(dt, w1, tuple(x.shape), 1, 1, g, extra=_carry_take(ctx.carry)) if ctx.needs_input_grad[0] else None   # + skip gradient (+ the input's stashed gradients)
         if not skip:
             dw1, db1 = wgrad_for_params(w1, b1, x, dt, 1, 1, ctx.has_b[0])
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None, None
 
     @staticmethod
     def _backward_planes(ctx, g):
@@ -1579,10 +1590,12 @@ class _RabBlock(Function):
                 plane_pool.put(x_pp, (main,))
         if slots and x_pp is None:                        # the trunk's first block = the backward's last: no further slot will come
             release_ready_pair(len(_state.ready_pairs))
-        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None
+        if ctx.group_first:
+            flush_pending_pp()                            # a launch never straddles ResGroups: what the exchange's group-boundary flush finds is the same with and without it
+        return dx, dw1, db1, dw2, db2, dfc1, dfc2, dw7, dwc, dbc, None, None, None, None
 
 
-def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
+def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False, group_first=False):
     if _tail_eval_ok(x):                                 # inference: three conv-sized launches + the pooling partials per block
         _require_gpu(x, 'rab_block')
         x = nhwc(x)
@@ -1608,7 +1621,8 @@ def rab_block(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, emit_pp=False):
     tag = getattr(x, '_srhip_pp', None) if _X_PP else None
     if tag is not None and tag[1] == x._version and tag[0].shape == tuple(x.shape):
         x_pp = tag[0]
-    out = _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp, bool(emit_pp and _X_PP), getattr(x, '_srhip_carry', None) if _CARRY else None)
+    out = _RabBlock.apply(x, w1, b1, w2, b2, fc1_w, fc2_w, w7, wc, bc, x_pp, bool(emit_pp and _X_PP), getattr(x, '_srhip_carry', None) if _CARRY else None,
+                          bool(group_first))
     pp, _state.last_out_pp = getattr(_state, 'last_out_pp', None), None
     if pp is not None:
         out._srhip_pp = (pp, out._version)
