@@ -12,9 +12,9 @@ dev = torch.device('cuda:0')
 N = int(os.environ.get('STEPS', '150'))
 
 
-def run():
+def run(sync=None):
     G, D, F = bench.build_networks(dev, 20240)
-    step = TrainStep(G, D, F)
+    step = TrainStep(G, D, F, grad_sync=sync)
     gen = torch.Generator().manual_seed(7)
     traj = []
     for it in range(N):
@@ -33,4 +33,14 @@ b_t, b_w = run()
 bad = (a_t != b_t).any(dim=1).nonzero().flatten().tolist()
 print('steps: %d, finite: %s, first differing step: %s, weights identical: %s' % (N, bool(torch.isfinite(a_t).all()), bad[:1] or None, bool(torch.equal(a_w, b_w))))
 print('last losses', a_t[-1].tolist())
+if os.environ.get('RCCL') == '1':       # round 6: the same 150 iterations with the gradient exchange on a single-rank RCCL communicator (the generator's
+    from sradsgan_amd import dp         # arena in parts from inside the backward, enqueue thread): a one-rank sum is the identity, so the trajectory must not move
+    sync = dp.GradSync(1, force=True)
+    c_t, c_w = run(sync)
+    sync.close()
+    badc = (a_t != c_t).any(dim=1).nonzero().flatten().tolist()
+    print('forced single-rank RCCL exchange: first differing step: %s, weights identical: %s, parts of the last step: %s'
+          % (badc[:1] or None, bool(torch.equal(a_w, c_w)), [(t, p) for t, p, _, _ in sync.parts[-5:]]))
+    if badc or not torch.equal(a_w, c_w):
+        sys.exit(1)
 sys.exit(0 if (not bad and torch.equal(a_w, b_w) and torch.isfinite(a_t).all()) else 1)
