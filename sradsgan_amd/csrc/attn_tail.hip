@@ -227,6 +227,16 @@ __global__ __launch_bounds__(256) void slam_pool_mlp_kernel(const float* __restr
   __shared__ __attribute__((aligned(16))) float s_l[TC];
   const int b = blockIdx.y, c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const bool writer = blockIdx.x == 0;
+  // the block's first NPRE pixel groups are fetched BEFORE the MLP: its chain of dependent loads, four barriers and an expf (~6 us) then runs
+  // under the latency of the pooling pass's own operands instead of in front of it (the first form of this kernel took as long as the two launches)
+  constexpr int NPRE = 8;
+  const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
+  float4 upre[NPRE];
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
+    upre[i] = p < hw ? *reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   {
     float sum = 0.f, m = -INFINITY;
     int am = 0x7fffffff;
@@ -302,11 +312,9 @@ __global__ __launch_bounds__(256) void slam_pool_mlp_kernel(const float* __restr
     }
     __syncthreads();
   }
-  const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
   const float4 sc = *reinterpret_cast<const float4*>(s_l + cq * 4);
-  for (int p = blockIdx.x * 16 + pl; p < hw; p += (int)gridDim.x * 16) {      // (the 16 lanes of a pixel share p: uniform for the row operations below)
+  auto pool_pixel = [&](const float4& v, int p) {                                 // (the 16 lanes of a pixel share p: the row operations see whole rows)
     const long pix = (long)b * hw + p;
-    const float4 v = *reinterpret_cast<const float4*>(u + pix * TC + cq * 4);
     const float y0 = v.x * sc.x, y1 = v.y * sc.y, y2 = v.z * sc.z, y3 = v.w * sc.w;
     float sum = (y0 + y1) + (y2 + y3);
     float mxv = y0;
@@ -328,7 +336,14 @@ __global__ __launch_bounds__(256) void slam_pool_mlp_kernel(const float* __restr
       pooled[pix] = make_float2(sum / (float)TC, mxv);
       argc[pix] = am;
     }
+  };
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
+    if (p < hw) pool_pixel(upre[i], p);
   }
+  for (int p = ((int)blockIdx.x + NPRE * (int)gridDim.x) * 16 + pl; p < hw; p += (int)gridDim.x * 16)
+    pool_pixel(*reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4), p);
 }
 
 // ---- F3: m = sigmoid(conv7x7 pad 3 (2 -> 1, no bias)(pooled)) ------------------------------------- //

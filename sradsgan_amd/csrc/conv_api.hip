@@ -125,6 +125,7 @@ extern int g_conv_math;
 extern int g_sgam_cfg;
 extern int g_pers_grid;
 extern int g_pers_small;
+extern int g_pool_epi_any;
 extern int g_pers_abl;
 extern int g_phase_batch;
 extern int g_headconv_rows;
@@ -270,6 +271,10 @@ int srhip_debug_set(int key, int value) {
   }
   if (key == 18) {
     g_headconv_rows = value;
+    return SRHIP_OK;
+  }
+  if (key == 19) {
+    g_pool_epi_any = value;
     return SRHIP_OK;
   }
   return SRHIP_ERR_ARG;

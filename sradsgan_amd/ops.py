@@ -789,6 +789,8 @@ if os.environ.get('SRHIP_PERS_GRID'):                          # experiment: blo
     _hip.lib().srhip_debug_set(5, int(os.environ['SRHIP_PERS_GRID']))
 if os.environ.get('SRHIP_FLAT_BLOCKS'):                        # experiment: blocks of the 8-wave weight-gradient kernel (default: one per CU)
     _hip.lib().srhip_debug_set(12, int(os.environ['SRHIP_FLAT_BLOCKS']))
+if os.environ.get('SRHIP_POOL_EPI_ANY'):                       # experiment: conv2's CLAM pooling epilogue at any launch size (B = 32: 768 tiles)
+    _hip.lib().srhip_debug_set(19, int(os.environ['SRHIP_POOL_EPI_ANY']))
 if os.environ.get('SRHIP_FLAT_F32_K8'):                       # experiment: 0 = a weight gradient with one fp32 operand takes the 4-wave flat kernel
     _hip.lib().srhip_debug_set(14, int(os.environ['SRHIP_FLAT_F32_K8']))
 if os.environ.get('SRHIP_TAIL_DBG'):                           # A/B knob: bit 32 = the round-5 launch sequence of the tail's backward (7x7 data gradient as its own launch)
