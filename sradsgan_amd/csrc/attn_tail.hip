@@ -232,22 +232,36 @@ __global__ __launch_bounds__(256) void slam_pool_mlp_kernel(const float* __restr
   constexpr int NPRE = 8;
   const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
   float4 upre[NPRE];
-#pragma unroll
-  for (int i = 0; i < NPRE; ++i) {
-    const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
-    upre[i] = p < hw ? *reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   {
+    // the MLP's own operands FIRST (loads return in order: issued behind the pixel groups they would wait for them), then the pixel groups
+    constexpr int MAXK = 16;                          // nseg <= POOL_MAXSEG = 64: at most 16 segments per quarter
+    float vs[MAXK], vm[MAXK];
+    int va[MAXK];
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = q + 4 * i;
+      const int o = (b * nseg + (k < nseg ? k : 0)) * TC + c;
+      vs[i] = psum[o];
+      vm[i] = pmax[o];
+      va[i] = parg[o];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
+      upre[i] = p < hw ? *reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    asm volatile("" ::: "memory");
     float sum = 0.f, m = -INFINITY;
     int am = 0x7fffffff;
-    for (int k = q; k < nseg; k += 4) {
-      const int o = (b * nseg + k) * TC + c;
-      sum += psum[o];
-      const float v = pmax[o];
-      const int a = parg[o];
-      if (pool_merge_takes(v, a, m, am)) {
-        m = v;
-        am = a;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      if (q + 4 * i < nseg) {
+        sum += vs[i];
+        if (pool_merge_takes(vm[i], va[i], m, am)) {
+          m = vm[i];
+          am = va[i];
+        }
       }
     }
     qs[q][c] = sum;
