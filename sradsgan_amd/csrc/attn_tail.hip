@@ -210,156 +210,6 @@ __global__ void slam_pool_kernel(const float* __restrict__ u, const float* __res
   }
 }
 
-// ---- F1b + F2 in one launch (round 6) -------------------------------------------------------------------------------------------- //
-// In the generator's forward the tail is a serial chain of five launches on the one stream that runs; its small kernels cost their
-// dispatch latency, not their work (clam_mlp_kernel: 32 blocks, 6.5 us end to end for ~1 us of arithmetic; rocprofv3 trace of the step).
-// Here every block first computes s of ITS image -- clam_mlp_kernel's code, same order, so s is bit-identical; block 0 of an image
-// writes avg / max / arg / s for the backward -- and then pools its share of the image's pixels with s from LDS (slam_pool_kernel's
-// arithmetic).  grid = (blocks per image, B); the partials every block re-reads are 24 KB per image and sit in L2.
-__global__ __launch_bounds__(256) void slam_pool_mlp_kernel(const float* __restrict__ u, const float* __restrict__ psum,
-                                                             const float* __restrict__ pmax, const int* __restrict__ parg,
-                                                             const float* __restrict__ fc1, const float* __restrict__ fc2,
-                                                             float* __restrict__ avg, float* __restrict__ mx, int* __restrict__ arg,
-                                                             float* __restrict__ s, float2* __restrict__ pooled, int* __restrict__ argc,
-                                                             int hw, int hidden, int nseg) {
-  __shared__ float sa[TC], sm[TC], ha[16], hm[16], qs[4][TC], qm[4][TC];
-  __shared__ int qa[4][TC];
-  __shared__ __attribute__((aligned(16))) float s_l[TC];
-  const int b = blockIdx.y, c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const bool writer = blockIdx.x == 0;
-  // the block's first NPRE pixel groups are fetched BEFORE the MLP: its chain of dependent loads, four barriers and an expf (~6 us) then runs
-  // under the latency of the pooling pass's own operands instead of in front of it (the first form of this kernel took as long as the two launches)
-  constexpr int NPRE = 8;
-  const int pl = threadIdx.x >> 4, cq = threadIdx.x & 15;
-  float4 upre[NPRE];
-  {
-    // the MLP's own operands FIRST (loads return in order: issued behind the pixel groups they would wait for them), then the pixel groups
-    constexpr int MAXK = 16;                          // nseg <= POOL_MAXSEG = 64: at most 16 segments per quarter
-    float vs[MAXK], vm[MAXK];
-    int va[MAXK];
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      const int k = q + 4 * i;
-      const int o = (b * nseg + (k < nseg ? k : 0)) * TC + c;
-      vs[i] = psum[o];
-      vm[i] = pmax[o];
-      va[i] = parg[o];
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
-      upre[i] = p < hw ? *reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    asm volatile("" ::: "memory");
-    float sum = 0.f, m = -INFINITY;
-    int am = 0x7fffffff;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      if (q + 4 * i < nseg) {
-        sum += vs[i];
-        if (pool_merge_takes(vm[i], va[i], m, am)) {
-          m = vm[i];
-          am = va[i];
-        }
-      }
-    }
-    qs[q][c] = sum;
-    qm[q][c] = m;
-    qa[q][c] = am;
-    __syncthreads();
-    if (q == 0) {
-      sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) sum += qs[k][c];
-      m = qm[0][c];
-      am = qa[0][c];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        const float v = qm[k][c];
-        const int a = qa[k][c];
-        if (pool_merge_takes(v, a, m, am)) {
-          m = v;
-          am = a;
-        }
-      }
-      const float a_ = sum / (float)hw;
-      if (writer) {
-        avg[b * TC + c] = a_;
-        mx[b * TC + c] = m;
-        arg[b * TC + c] = am;
-      }
-      sa[c] = a_;
-      sm[c] = m;
-    }
-    __syncthreads();
-    {
-      const int j = threadIdx.x >> 4, part = threadIdx.x & 15;
-      float x0 = 0.f, x1 = 0.f;
-      if (j < hidden) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float w = fc1[j * TC + part * 4 + k];
-          x0 += w * sa[part * 4 + k];
-          x1 += w * sm[part * 4 + k];
-        }
-      }
-      x0 = group16_sum(x0);
-      x1 = group16_sum(x1);
-      if (j < hidden && part == 0) {
-        ha[j] = x0 < 0.f ? 0.f : x0;
-        hm[j] = x1 < 0.f ? 0.f : x1;
-      }
-    }
-    __syncthreads();
-    if (q == 0) {
-      float l0 = 0.f, l1 = 0.f;
-      for (int j = 0; j < hidden; ++j) {
-        const float w = fc2[c * hidden + j];
-        l0 += w * ha[j];
-        l1 += w * hm[j];
-      }
-      const float l = l0 + l1;
-      const float sv = 1.f / (1.f + expf(-l));
-      s_l[c] = sv;
-      if (writer) s[b * TC + c] = sv;
-    }
-    __syncthreads();
-  }
-  const float4 sc = *reinterpret_cast<const float4*>(s_l + cq * 4);
-  auto pool_pixel = [&](const float4& v, int p) {                                 // (the 16 lanes of a pixel share p: the row operations see whole rows)
-    const long pix = (long)b * hw + p;
-    const float y0 = v.x * sc.x, y1 = v.y * sc.y, y2 = v.z * sc.z, y3 = v.w * sc.w;
-    float sum = (y0 + y1) + (y2 + y3);
-    float mxv = y0;
-    int am = cq * 4;
-    if (pool_takes(y1, mxv)) { mxv = y1; am = cq * 4 + 1; }
-    if (pool_takes(y2, mxv)) { mxv = y2; am = cq * 4 + 2; }
-    if (pool_takes(y3, mxv)) { mxv = y3; am = cq * 4 + 3; }
-    sum = group16_sum(sum);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(mxv, o, 16);
-      const int oa = __shfl_xor(am, o, 16);
-      if (pool_merge_takes(ov, oa, mxv, am)) {
-        mxv = ov;
-        am = oa;
-      }
-    }
-    if (cq == 0) {
-      pooled[pix] = make_float2(sum / (float)TC, mxv);
-      argc[pix] = am;
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < NPRE; ++i) {
-    const int p = ((int)blockIdx.x + i * (int)gridDim.x) * 16 + pl;
-    if (p < hw) pool_pixel(upre[i], p);
-  }
-  for (int p = ((int)blockIdx.x + NPRE * (int)gridDim.x) * 16 + pl; p < hw; p += (int)gridDim.x * 16)
-    pool_pixel(*reinterpret_cast<const float4*>(u + ((long)b * hw + p) * TC + cq * 4), p);
-}
-
 // ---- F3: m = sigmoid(conv7x7 pad 3 (2 -> 1, no bias)(pooled)) ------------------------------------- //
 __global__ void slam_conv7_kernel(const float2* __restrict__ pooled, const float* __restrict__ w7,
                                   float* __restrict__ m, int h, int w, long npix) {
@@ -1093,17 +943,8 @@ static int tail_fwd_impl(const float* u, const float* psum, const float* pmax, c
                          int w, int hidden, hipStream_t st) {
   const int hw = h * w;
   const long npix = (long)n * hw;
-  if (!(g_tail_dbg & 64)) {                          // round 6: the channel MLP inside the pooling pass (srhip_debug_set(7, 64): the two launches of rounds 2-5)
-    const int ngroups = (hw + 15) / 16;
-    int bpi = cdiv(3 * 256, n);                        // ~ three blocks per CU over the batch, at least 4 and at most one per 16-pixel group
-    if (bpi < 4) bpi = 4;
-    if (bpi > ngroups) bpi = ngroups;
-    hipLaunchKernelGGL(slam_pool_mlp_kernel, dim3(bpi, n), dim3(256), 0, st, u, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s,
-                       reinterpret_cast<float2*>(pooled), argc, hw, hidden, nseg);
-  } else {
-    hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(256), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden, nseg);
-    hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
-  }
+  hipLaunchKernelGGL(clam_mlp_kernel, dim3(n), dim3(256), 0, st, psum, pmax, parg, fc1, fc2, avg, mx, argmax_hw, s, hw, hidden, nseg);
+  hipLaunchKernelGGL(slam_pool_kernel, dim3(cdiv(npix, 16)), dim3(256), 0, st, u, s, reinterpret_cast<float2*>(pooled), argc, hw, npix);
   hipLaunchKernelGGL(slam_conv7_kernel, dim3(cdiv(npix, 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(pooled), w7, m, h, w, npix);
   return check_launch("attn_tail_fwd");
 }

@@ -724,7 +724,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 
 thread_local PoolRequest g_pool_req;
 thread_local SignRequest g_sign_req;
-int g_pool_epi_any = 0; // srhip_debug_set(19, 1): the CLAM pooling epilogue at any launch size (default: only while at most two blocks share a CU)
+int g_pool_epi_any = 1; // srhip_debug_set(19, 0): the CLAM pooling epilogue only while at most two blocks share a CU (rounds 4-5).  Round 6: at any launch size --
+                        // alone the epilogue's reduction costs the B = 32 conv what the stand-alone pooling pass takes (+5.8 against 6.0 us), in the generator's
+                        // forward that pass is a launch of its own in a serial chain on the one stream that runs: +0.35 % of the step (profiles/r06_step_ab.txt)
 int g_pers_small = 1;   // srhip_debug_set(11, v): 0 = launches with fewer tiles than block slots keep the one-tile kernels
 int g_pers_grid = 0;      // srhip_debug_set(5, n)
 int g_pers_abl = 0;       // srhip_debug_set(6, bits): timing-only ablations of conv_patch_pers_kernel<128, bias+lrelu>
@@ -861,9 +863,9 @@ int launch_patch_pers(const float* src, const float* wt, const float* bias, cons
   if (g_pool_req.out != nullptr && !wide && prod == 0 && nbn == 1 && g.K == 64 && (eflags == 0 || eflags == SRHIP_EPI_BIAS) &&
       2 * pg.tiles_h * pg.tiles_w <= POOL_MAXSEG && g.Hd == g.OH && g.Wd == g.OW &&
       (ntiles <= 2 * (slots / 3) || g_pers_grid > 0 || g_pool_epi_any)) {
-    // (only while at most two blocks share a CU: the reduction is ~600 VALU instructions per lane and tile at the exposed end of every
-    // block -- with 768 one-tile blocks (B = 32) it adds 5.8 us to the conv, as much as the 24 MB pooling pass it replaces takes;
-    // with 384 (B = 16) 2.8 us against 4.3-5.9: `tools/time_pool_epi.py`.  Larger launches leave the request to the pooling pass.)
+    // (the reduction is ~600 VALU instructions per lane and tile at the exposed end of every block -- with 768 one-tile blocks (B = 32) it
+    // adds 5.8 us to the conv, as much as the 24 MB pooling pass it replaces takes alone; with 384 (B = 16) 2.8 us against 4.3-5.9:
+    // `tools/time_pool_epi.py`.  Rounds 4-5 therefore left larger launches to the pooling pass; in the step the pass costs more than alone.)
     const int nseg = 2 * pg.tiles_h * pg.tiles_w;
     if ((size_t)g.N * nseg * 64 * 4 <= (size_t)g_pool_req.sec_bytes) {
       float* po = g_pool_req.out;

@@ -828,43 +828,6 @@ def test_tail_backward_with_the_7x7_data_gradient_inside_the_main_pass(shape):
         assert err < 2e-5, (name, err)
 
 
-@pytest.mark.parametrize('shape', [(2, 23, 37), (32, 54, 54), (1, 9, 20), (5, 108, 108), (3, 4, 5)])
-@pytest.mark.parametrize('from_conv', [False, True])
-def test_tail_forward_with_the_channel_mlp_inside_the_pooling_pass_is_bit_identical(shape, from_conv):
-    """Round 6: slam_pool_mlp_kernel -- every block of the SLAM pooling pass computes s = sigmoid(MLP(avg) + MLP(max)) of its image
-    itself (clam_mlp_kernel's code and order) instead of reading what a launch of its own wrote (sradsgan.py:117-127 in front of
-    :141-151): one launch less in the forward's serial chain.  Against the two launches of rounds 2-5 (srhip_debug_set(7, 64)): the
-    output and every tensor saved for the backward (avg, max, arg-max, s, pooled map, arg-max channel, m) bit-identical, with the CLAM
-    pooling partials from the stand-alone pass and from conv2's epilogue."""
-    from sradsgan_amd import _hip, ops
-    n, h, w = shape
-    g = torch.Generator().manual_seed(sum(shape) + 11)
-    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
-    skip = cl(torch.randn(n, 64, h, w, generator=g))
-    par = [p.to(DEV) for p in ((torch.randn(4, 64, 1, 1, generator=g) * 0.2), (torch.randn(64, 4, 1, 1, generator=g) * 0.2), (torch.randn(1, 2, 7, 7, generator=g) * 0.1),
-                                (torch.randn(64, 64, 1, 1, generator=g) * 0.1), (torch.randn(64, generator=g) * 0.1))]
-    pool = None
-    if from_conv:                                      # u = conv2(t) with the pooling partials left behind by its epilogue (where the launch serves them)
-        t = cl(torch.randn(n, 256, h, w, generator=g))
-        w2, b2 = (torch.randn(64, 256, 3, 3, generator=g) * 0.05).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
-        if not ops.pool_epilogue_ok(t, w2):
-            pytest.skip('conv2 epilogue pooling is a split-bf16 path')
-        u, pool = ops.conv2d_fwd_pool_raw(t, w2, b2)
-    else:
-        u = cl(torch.randn(n, 64, h, w, generator=g))
-    res = []
-    for old in (False, True):
-        _hip.lib().srhip_debug_set(7, 64 if old else 0)
-        try:
-            out, saved = ops._tail_forward(u, skip, *par, pool)
-            torch.cuda.synchronize()
-            res.append([out.clone()] + [t_.clone() for t_ in saved])
-        finally:
-            _hip.lib().srhip_debug_set(7, 0)
-    for a, b, name in zip(res[0], res[1], ['out', 'avg', 'max', 'arg', 's', 'pooled', 'argc', 'm']):
-        assert torch.equal(a, b), name
-
-
 def test_weight_gradient_slots_leave_the_training_step_bit_identical():
     """Round 6 experiment (ops.release_ready_pair, SRHIP_WGRAD_SLOTS): complete pairs of RAB weight gradients start in slots behind
     conv1's data gradient instead of the moment they complete.  Same kernels, same accumulation per parameter: one full iteration
