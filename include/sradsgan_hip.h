@@ -52,7 +52,8 @@ int srhip_stream_fork(void* from_stream, void* to_stream);
  * ABI 5: srhip_bn_eval_fwd, srhip_attn_tail_bwd (+ _fused_workspace), srhip_stream_fork, srhip_conv2d_wgrad_multi (+ _ok)
  *        added (no existing entry point changed).
  * ABI 6-9: see the notes at the entry points they added.
- * ABI 10: srhip_attn_tail_bwd_g REMOVED (nothing else changed). */
+ * ABI 10: srhip_attn_tail_bwd_g REMOVED (nothing else changed).
+ * ABI 11: srhip_cat_channels / srhip_split_channels added. */
 /* Experiment knobs for kernel tuning and for tests that must reach a specific kernel at a small size:
  *   key 0  fprop/dgrad kernel choice: 0 heuristic, -1 force the LDS-DMA kernels, -2 force the patch kernel,
  *          20 / 21 register-staged (exact fp32) kernels only, 23 every launch the patch kernel would take goes to the LDS-DMA kernel,
@@ -251,6 +252,10 @@ int srhip_lrelu_bwd_bits(const float* dy, const float* y, void* mask, float* dx,
  * the stratified dense-sampling bus of GeneratorResNet.forward (sradsgan.py:455-460: `bus = bus + out` after every residual
  * group) in one pass, same summation order as the chained torch adds it replaces.                                            */
 int srhip_sum_n(const float* const* srcs, int n, float* out, long count, void* stream);
+/* ABI 11: torch.cat(dim = 1) of n = 2..8 NHWC tensors with `rows` pixel rows each and chans[k] channels (multiples of 4, 16-byte aligned
+ * tensors) -- the multi-scale block's three branches, sradsgan.py:340-344 -- and its backward: the wide tensor split back into n dense ones. */
+int srhip_cat_channels(const float* const* srcs, const int* chans, int n, float* out, long rows, void* stream);
+int srhip_split_channels(const float* in, const int* chans, int n, float* const* dsts, long rows, void* stream);
 /* nn.MaxPool2d(2,2) of vgg19.features[4] / [9] (sradsgan.py:92-95) on NHWC, even H and W, C % 4 == 0.
  * bwd recomputes the argmax from x (first maximum in window scan order, like ATen); relu_input != 0
  * also applies the backward of the ReLU that produced x (dx = 0 where the window maximum is 0).   */

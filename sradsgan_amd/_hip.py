@@ -120,6 +120,8 @@ SIGNATURES = {
     'srhip_attn_tail_fwd_pooled': (_i, [_vp, _vp, _sz, _i] + [_vp] * 10 + [_i] * 5 + [_vp]),
     'srhip_attn_tail_eval_pooled': (_i, [_vp, _vp, _vp, _sz, _i] + [_vp] * 6 + [_i] * 5 + [_vp]),
     'srhip_sum_n': (_i, [_vp, _i, _vp, _l, _vp]),
+    'srhip_cat_channels': (_i, [_vp, _vp, _i, _vp, _l, _vp]),
+    'srhip_split_channels': (_i, [_vp, _vp, _i, _vp, _l, _vp]),
     'srhip_bn_train_bwd_acc': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_acc_x': (_i, [_vp] * 12 + [_sz, _l, _i, _f, _i, _vp]),
     'srhip_bn_train_bwd_acc_xa': (_i, [_vp] * 13 + [_sz, _l, _i, _f, _i, _vp]),

@@ -179,7 +179,7 @@ class MSB(nn.Module):
         self.conv = HipConv2d(planes * 3, planes, kernel_size=1, bias=True)
 
     def forward(self, x):
-        cat = torch.cat([self.conv1(x), self.conv2(x), self.conv3(x)], dim=1)
+        cat = ops.cat_channels([self.conv1(x), self.conv2(x), self.conv3(x)])      # torch.cat(dim=1) in one pass (srhip_cat_channels)
         return self.conv(cat, act_slope=0.01)
 
 

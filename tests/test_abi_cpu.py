@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_pure_host_entry_points(lib):
-    assert lib.srhip_abi_version() >= 10
+    assert lib.srhip_abi_version() >= 11
     # fast n-major layout: fp32 | split-bf16 | fp16 sections + the tiled split-bf16 section (destination channels padded to 16)
     assert lib.srhip_packed_elems(256, 64, 3, 3, 0) == 3 * 256 * 64 * 9 + 9 * 64 * 256
     assert lib.srhip_packed_elems(64, 3, 3, 3, 0) == 27 * 64                 # generic k-major, ld = 64

@@ -828,6 +828,27 @@ def test_tail_backward_with_the_7x7_data_gradient_inside_the_main_pass(shape):
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize('case', [((2, 13, 17), (64, 64, 64)), ((32, 54, 54), (64, 64, 64)), ((1, 5, 3), (4, 128, 8, 36)), ((3, 9, 9), (64, 192))])
+def test_cat_channels_is_torch_cat(case):
+    """srhip_cat_channels / srhip_split_channels (ABI 11): torch.cat(dim=1) of NHWC tensors and its backward in one pass each -- the
+    multi-scale block's concatenation (sradsgan.py:340-344).  Data movement only: output and gradients equal torch's bit for bit."""
+    from sradsgan_amd import ops
+    (n, h, w), chans = case
+    g = torch.Generator().manual_seed(sum(chans) + n)
+    xs = [torch.randn(n, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last) for c in chans]
+    dy = torch.randn(n, sum(chans), h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    a = [x.clone().requires_grad_(True) for x in xs]
+    b = [x.clone().requires_grad_(True) for x in xs]
+    ya = ops.cat_channels(a)
+    yb = torch.cat(b, dim=1)
+    assert type(ya.grad_fn).__name__.startswith('_CatChannels')          # the HIP path ran
+    assert torch.equal(ya, yb)
+    ya.backward(dy)
+    yb.backward(dy)
+    for p, q in zip(a, b):
+        assert torch.equal(p.grad, q.grad)
+
+
 def test_weight_gradient_slots_leave_the_training_step_bit_identical():
     """Round 6 experiment (ops.release_ready_pair, SRHIP_WGRAD_SLOTS): complete pairs of RAB weight gradients start in slots behind
     conv1's data gradient instead of the moment they complete.  Same kernels, same accumulation per parameter: one full iteration
